@@ -1,0 +1,129 @@
+/* libr2dm_hip.so -- C ABI of the MI355X (gfx950) R2DM sampling engine.
+ *
+ * The reference (kazuto1011/r2dm) has no native code and no FFI; its only seam on the sampling path
+ * is the Python call  prediction = self.model(x_t, cond)  plus the elementwise posterior update
+ * around it.  This header is that seam expressed as a C ABI: what a ctypes / cffi / pybind stub in
+ * the reference would bind to run the per-step hot path on hand-written HIP kernels.
+ * Every entry point names the reference code it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - all tensors are fp32, NCHW, contiguous, in DEVICE memory owned by the caller (PyTorch);
+ *   - the library never allocates device memory, never synchronises and enqueues everything on the
+ *     `stream` it is given (a hipStream_t passed as void*; NULL = default stream);
+ *   - a handle is bound to the current device of the creating thread and used from one host thread;
+ *   - every function returns 0 on success and a non-zero code on failure; r2dm_last_error() then
+ *     returns a thread-local human-readable message.
+ */
+#ifndef R2DM_HIP_H
+#define R2DM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct r2dm_handle r2dm_handle;
+
+/* Geometry of one EfficientUNet instance: the constructor arguments of
+ * models/efficient_unet.py:194-211 that shape tensors (ring=True, dropout=0 always). */
+typedef struct r2dm_config {
+    int32_t in_channels;            /* 2: range + reflectance */
+    int32_t out_channels;
+    int32_t height, width;          /* resolution, e.g. 64 x 1024 */
+    int32_t base_channels;          /* 64 */
+    int32_t temb_channels;          /* 4 * base */
+    int32_t channel_multiplier[4];  /* (1,2,4,8) */
+    int32_t num_residual_blocks[4]; /* (3,3,3,3) */
+    int32_t gn_num_groups;          /* 8 */
+    float gn_eps;                   /* 1e-6 */
+    int32_t attn_num_heads;         /* 8 */
+    int32_t coord_channels;         /* channels of the constant coordinate encoding (32 @64x1024; 0 = none) */
+    int32_t max_batch;              /* layer tilings are chosen for batches up to this size */
+} r2dm_config;
+
+/* One state-dict tensor the engine consumes, in the reference's naming (SURVEY.md appendix A.3,
+ * without the "model." prefix), plus two host-precomputed constants:
+ *   "__cenc"      (coord_channels, H, W)  FourierFeatures(coords)        models/encoding.py:141-146
+ *   "__sin_freqs" (base_channels/2,)      sinusoid frequency table       models/ops.py:22-23          */
+typedef struct r2dm_tensor_info {
+    const char* key;
+    int64_t numel; /* number of fp32 elements the caller must supply */
+} r2dm_tensor_info;
+
+const char* r2dm_last_error(void);
+const char* r2dm_version(void);
+
+/* -- lifetime ------------------------------------------------------------------------------- */
+int r2dm_create(r2dm_handle** out, const r2dm_config* cfg);
+void r2dm_destroy(r2dm_handle* h);
+
+/* -- weights: replaces nn.Module.load_state_dict + .to(device) for the denoiser
+ *    (utils/inference.py:80-83).  The caller allocates r2dm_blob_bytes() of device memory, binds it,
+ *    then feeds every tensor listed by r2dm_tensor_at(); the engine repacks each into its
+ *    kernel-friendly layout inside the blob (HIP kernels, asynchronous).  A blob filled on one GPU
+ *    can be broadcast (RCCL) and bound on another GPU with an identical config: no per-rank load. */
+int64_t r2dm_num_tensors(const r2dm_handle* h);
+int r2dm_tensor_at(const r2dm_handle* h, int64_t index, r2dm_tensor_info* out);
+size_t r2dm_blob_bytes(const r2dm_handle* h);
+int r2dm_bind_blob(r2dm_handle* h, void* dev_blob, size_t bytes);
+int r2dm_load_tensor(r2dm_handle* h, int64_t index, const float* dev_src, int64_t numel, void* stream);
+
+/* -- the denoiser: replaces EfficientUNet.forward (models/efficient_unet.py:269-295), called from
+ *    p_step at models/diffusion/continuous_time.py:207 and discrete_time.py:139.
+ *    x (B,in_channels,H,W), cond (B,) as float, out (B,out_channels,H,W). */
+size_t r2dm_workspace_bytes(const r2dm_handle* h, int32_t batch);
+int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t batch,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* -- posterior update: replaces the elementwise tail of p_step
+ *    (continuous_time.py:208-229, discrete_time.py:140-177).  coef is (B,8) host-computed scalars,
+ *    see r2dm_amd/diffusion.py for the slot meaning per mode.
+ *    mode: 0 continuous DDPM, 1 continuous DDIM, 2 discrete DDPM, 3 discrete DDIM (eta=0, noise may
+ *    be NULL), 4 discrete DDIM with noise.  objective: 0 eps, 1 v, 2 x_0.  clip < 0 disables clamping. */
+int r2dm_posterior_step(const float* x_t, const float* prediction, const float* noise, const float* coef,
+                        float* x_s, int32_t batch, int64_t per_sample, int32_t mode, int32_t objective,
+                        float clip, void* stream);
+
+/* -- sample post-processing: LiDARUtility.denormalize/revert_depth/to_xyz + concat
+ *    (utils/lidar.py:49-61,98-120; sample_and_save.py:52-57).  x (B,2,H,W) in [-1,1],
+ *    ray_angles (2,H,W) [elevation, azimuth] in rad, out (B,5,H,W) = depth,x,y,z,reflectance. */
+int r2dm_lidar_postprocess(const float* x, const float* ray_angles, float* out, int32_t batch, int32_t height,
+                           int32_t width, float min_depth, float max_depth, void* stream);
+
+/* -- single kernels, exported for per-op parity tests against the oracle -------------------- */
+/* ops.Conv2d(ring) 3x3 / 1x1 (models/ops.py:149-173) with optional fused GroupNorm-affine(+SiLU)
+ * prologue (aff: (B,Cin,2) or NULL; prologue 0 none, 1 affine, 2 affine+SiLU) and optional
+ * residual-add + scale epilogue.  w is OIHW; w_packed is caller scratch of r2dm_conv_packed_elems(). */
+int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t batch, int32_t height,
+                               int32_t width);
+int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w_packed, const float* aff,
+                     int32_t prologue, const float* residual, const float* scale, float* y, int32_t batch,
+                     int32_t cin, int32_t cout, int32_t height, int32_t width, int32_t ksize, void* stream);
+/* nn.GroupNorm / AdaGN statistics folded to y = x*a + d (models/efficient_unet.py:72; ops.py:176-200).
+ * gamma/beta (C,) or NULL; ada (B,2C) [scale|shift] or NULL; partial: scratch of
+ * r2dm_group_norm_scratch_bytes(); aff out (B,C,2); stats out (B,G,2) mean/rstd or NULL. */
+size_t r2dm_group_norm_scratch_bytes(int32_t batch, int32_t groups);
+int r2dm_group_norm_affine(const float* x, const float* gamma, const float* beta, const float* ada, void* scratch,
+                           float* aff, float* stats, int32_t batch, int32_t channels, int32_t height,
+                           int32_t width, int32_t groups, float eps, void* stream);
+int r2dm_affine_act(const float* x, const float* aff, float* y, int32_t batch, int32_t channels, int64_t hw,
+                    int32_t silu, void* stream);
+/* ops.Resample(down=2) / (up=2) (models/ops.py:52-146) */
+int r2dm_fir_down2(const float* x, float* y, int32_t batch, int32_t channels, int32_t height, int32_t width,
+                   void* stream);
+int r2dm_fir_up2(const float* x, float* y, int32_t batch, int32_t channels, int32_t height, int32_t width,
+                 void* stream);
+/* attention core of nn.MultiheadAttention on channel-major qkv (B,3C,N) -> (B,C,N)
+ * (models/efficient_unet.py:34-38,46) */
+int r2dm_attention(const float* qkv, float* out, int32_t batch, int32_t channels, int32_t heads, int32_t tokens,
+                   void* stream);
+/* time embedding: cond (B,) -> SiLU(time_embedding(cond)) (B,T)  (models/efficient_unet.py:232-237) */
+int r2dm_time_embedding(const float* cond, const float* freqs, const float* w1, const float* b1, const float* w2,
+                        const float* b2, float* act, int32_t batch, int32_t base, int32_t temb, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R2DM_HIP_H */

@@ -1,0 +1,126 @@
+// Shared declarations for libr2dm_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace r2dm {
+
+constexpr int kWave = 64;  // CDNA wavefront
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// A (B, C0+C1, H, W) activation that may live in two allocations (channel concat without a copy,
+// reference efficient_unet.py:11-12,290-292).  Planes are H*W contiguous floats; `bs` is the batch
+// stride in floats (0 = broadcast over the batch, used for the constant coordinate encoding).
+struct Src {
+    const float* p0;
+    const float* p1;
+    int c0, c1;
+    long bs0, bs1;
+    __host__ __device__ int channels() const { return c0 + c1; }
+    __device__ __forceinline__ const float* plane(int b, int c, long hw) const {
+        return c < c0 ? p0 + b * bs0 + (long)c * hw : p1 + b * bs1 + (long)(c - c0) * hw;
+    }
+};
+
+__device__ __forceinline__ float silu_f(float v) {
+    // x * sigmoid(x) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each).  Absolute error
+    // <= ~2e-7*|v|, i.e. fp32-roundoff class like the convolution it feeds (parity budget ~1e-6).
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+
+// XCD-aware bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): logical ids that
+// are neighbours (share input halo / weights) land on the same XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+// ---- kernel launchers (each in its own .hip) ------------------------------------------
+
+enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2 };
+
+struct ConvParams {
+    Src x;               // input activation
+    const float* w;      // packed weights [nCoT][CinPad][taps][CO_T]
+    const float* bias;   // [Cout]
+    const float2* aff;   // [B][Cin] (a, d): GroupNorm folded to x*a+d, or nullptr
+    const float* res;    // residual added before scaling, Cout planes, or nullptr
+    long res_bs;
+    const float* scale;  // device scalar multiplied after the residual add, or nullptr
+    float* y;            // output, Cout planes
+    long y_bs;
+    int B, H, W, Cin, CinPad, Cout;
+    int taps;            // 9 or 1
+    int co_tile;         // 32 / 64 / 128 (must match the packing)
+    int prologue;        // Prologue
+};
+int conv_pick_co_tile(int Cout, int taps, long pixels_times_batch);
+int conv_cin_pad(int Cin, int taps, int co_tile);
+hipError_t launch_conv(const ConvParams& p, hipStream_t s);
+hipError_t launch_pack_conv(const float* w_oihw, float* dst, int Cout, int Cin, int taps, int co_tile,
+                            int cin_pad, hipStream_t s);
+
+struct GNParams {
+    Src x;
+    int B, H, W, groups;
+    float eps;
+    const float* gamma;  // [C] or nullptr  (affine GroupNorm)
+    const float* beta;
+    const float* ada;    // [B][ada_stride] rows = [scale(C) | shift(C)] or nullptr (AdaGN)
+    long ada_stride;
+    double* partial;     // scratch [B][G][splits][2]
+    float2* aff;         // out [B][C]
+    float* stats;        // optional out [B][G][2] (mean, rstd) for tests, may be nullptr
+};
+int gn_splits(int B, int groups, long group_elems);
+hipError_t launch_group_norm(const GNParams& p, hipStream_t s);
+hipError_t launch_gn_apply(const float* x, const float2* aff, float* y, int B, int C, long hw, int silu,
+                           hipStream_t s);
+
+hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
+                            hipStream_t s);
+hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
+                          hipStream_t s);
+
+// qkv: (B, 3C, N) channel-major [q | k | v]; out (B, C, N)
+hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s);
+bool attention_supported(int C, int heads, int N);
+
+struct EmbedParams {
+    const float* cond;  // [B]
+    const float* freqs; // [base/2] sinusoid frequencies (host-precomputed)
+    const float* w1;    // [T][base]
+    const float* b1;
+    const float* w2;    // [T][T]
+    const float* b2;
+    float* act;         // out [B][T] = SiLU(time embedding)
+    int B, base, T;
+};
+hipError_t launch_time_embedding(const EmbedParams& p, hipStream_t s);
+// out[b][r] = dot(act[b], w[r]) + bias[r]   for all AdaGN projections at once
+hipError_t launch_ada_proj(const float* act, const float* w, const float* bias, float* out, int B, int T,
+                           int rows, hipStream_t s);
+
+struct PosteriorParams {
+    const float* x_t;
+    const float* pred;
+    const float* noise;  // may be nullptr for deterministic modes
+    const float* coef;   // [B][8]
+    float* x_s;
+    int B;
+    long per_sample;
+    int mode, objective;
+    float clip;  // < 0: no clamping
+};
+hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s);
+
+// (B,2,H,W) in [-1,1] -> (B,5,H,W) [depth, x, y, z, reflectance]  (reference sample_and_save.py:52-57)
+hipError_t launch_lidar_postprocess(const float* x, const float* angles, float* y, int B, int H, int W,
+                                    float min_depth, float max_depth, hipStream_t s);
+
+}  // namespace r2dm

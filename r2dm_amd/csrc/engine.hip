@@ -1,0 +1,648 @@
+// C ABI (include/r2dm_hip.h) and the U-Net execution plan.
+//
+// r2dm_unet_forward replaces EfficientUNet.forward (/root/reference/models/efficient_unet.py:269-295):
+// it walks the eight U-Net stages and enqueues the HIP kernels of this library on the caller's
+// stream.  Nothing here allocates or synchronises: weights live in a caller-owned blob, activations
+// in a caller-owned workspace carved by a deterministic first-fit arena (the same walk run "dry"
+// yields r2dm_workspace_bytes).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/r2dm_hip.h"
+#include "common.h"
+
+using namespace r2dm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
+
+// ---- plan -----------------------------------------------------------------------------------
+struct ConvLayer {
+    int cin = 0, cout = 0, taps = 0, co_tile = 0, cin_pad = 0;
+    size_t w = 0, b = 0;  // blob offsets in floats
+    size_t packed_elems() const { return (size_t)((cout + co_tile - 1) / co_tile) * cin_pad * taps * co_tile; }
+};
+
+struct ResLayer {
+    int cin = 0, cout = 0;
+    size_t g1 = 0, b1 = 0, scale = 0;
+    int ada_row = 0;  // first row of this block's [scale|shift] projection in the packed matrix
+    ConvLayer conv1, conv2, skip;
+    bool has_skip = false;
+};
+
+struct AttnLayer {
+    int C = 0;
+    size_t gamma = 0, beta = 0, scale = 0;
+    ConvLayer qkv, proj;
+};
+
+struct Stage {
+    std::string name;
+    int cin = 0, cout = 0;
+    bool down = false, up = false, attn = false;
+    ConvLayer dconv, uconv;
+    std::vector<ResLayer> res;
+    AttnLayer at;
+};
+
+enum SlotKind { SLOT_RAW, SLOT_CONV };
+struct Slot {
+    std::string key;
+    int64_t numel;
+    SlotKind kind;
+    size_t off;  // destination offset in floats
+    ConvLayer conv;  // for SLOT_CONV
+};
+
+}  // namespace
+
+struct r2dm_handle {
+    r2dm_config cfg;
+    int device = 0;
+    std::vector<Slot> slots;
+    size_t blob_floats = 0;
+    float* blob = nullptr;
+    Stage stages[8];
+    ConvLayer in_conv, out_conv;
+    size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
+    int ada_rows = 0;
+    std::map<int, size_t> ws_cache;
+
+    size_t take(size_t floats) {
+        const size_t off = blob_floats;
+        blob_floats += align_up(floats * sizeof(float)) / sizeof(float);
+        return off;
+    }
+    size_t raw(const std::string& key, int64_t numel) {
+        const size_t off = take(numel);
+        slots.push_back({key, numel, SLOT_RAW, off, {}});
+        return off;
+    }
+    void raw_at(const std::string& key, int64_t numel, size_t off) { slots.push_back({key, numel, SLOT_RAW, off, {}}); }
+    ConvLayer conv(const std::string& wkey, const std::string& bkey, int cin, int cout, int ksize, long px_batch) {
+        ConvLayer L;
+        L.cin = cin;
+        L.cout = cout;
+        L.taps = ksize * ksize;
+        L.co_tile = conv_pick_co_tile(cout, L.taps, px_batch);
+        L.cin_pad = conv_cin_pad(cin, L.taps, L.co_tile);
+        L.w = take(L.packed_elems());
+        slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
+        L.b = raw(bkey, cout);
+        return L;
+    }
+};
+
+namespace {
+
+void build_plan(r2dm_handle* h) {
+    const r2dm_config& c = h->cfg;
+    const int C0 = c.base_channels, T = c.temb_channels;
+    int Cl[5] = {C0, C0 * c.channel_multiplier[0], C0 * c.channel_multiplier[1], C0 * c.channel_multiplier[2],
+                 C0 * c.channel_multiplier[3]};
+    const long px1 = (long)c.height * c.width * c.max_batch;
+
+    if (c.coord_channels > 0) h->cenc = h->raw("__cenc", (int64_t)c.coord_channels * c.height * c.width);
+    h->freqs = h->raw("__sin_freqs", C0 / 2);
+    h->w1 = h->raw("time_embedding.1.weight", (int64_t)T * C0);
+    h->b1 = h->raw("time_embedding.1.bias", T);
+    h->w2 = h->raw("time_embedding.3.weight", (int64_t)T * T);
+    h->b2 = h->raw("time_embedding.3.bias", T);
+    h->in_conv = h->conv("in_conv.weight", "in_conv.bias", c.in_channels + c.coord_channels, C0, 3, px1);
+
+    struct Def { const char* name; int cin, cout, n, level; bool down, up, attn; };
+    const Def defs[8] = {
+        {"d_block1", Cl[0], Cl[1], c.num_residual_blocks[0], 0, false, false, false},
+        {"d_block2", Cl[1], Cl[2], c.num_residual_blocks[1], 1, true, false, false},
+        {"d_block3", Cl[2], Cl[3], c.num_residual_blocks[2], 2, true, false, false},
+        {"d_block4", Cl[3], Cl[4], c.num_residual_blocks[3], 3, true, false, true},
+        {"u_block4", Cl[4], Cl[3], c.num_residual_blocks[3], 3, false, true, true},
+        {"u_block3", 2 * Cl[3], Cl[2], c.num_residual_blocks[2], 2, false, true, false},
+        {"u_block2", 2 * Cl[2], Cl[1], c.num_residual_blocks[1], 1, false, true, false},
+        {"u_block1", 2 * Cl[1], Cl[0], c.num_residual_blocks[0], 0, false, false, false},
+    };
+    // count AdaGN rows first so the projection matrix is one contiguous [rows][T] block
+    int rows = 0;
+    for (const Def& d : defs) rows += d.n * 2 * d.cout;
+    h->ada_rows = rows;
+    h->ada_w = h->take((size_t)rows * T);
+    h->ada_b = h->take(rows);
+
+    int row = 0;
+    for (int s = 0; s < 8; ++s) {
+        const Def& d = defs[s];
+        Stage& st = h->stages[s];
+        st.name = d.name;
+        st.cin = d.cin;
+        st.cout = d.cout;
+        st.down = d.down;
+        st.up = d.up;
+        st.attn = d.attn;
+        const long px = px1 >> (2 * d.level);  // pixels*batch at the level the residual blocks run on
+        const std::string p = std::string(d.name) + ".";
+        if (d.down)  // the stage's first conv runs at the resolution above (efficient_unet.py:132-136)
+            st.dconv = h->conv(p + "downsample.0.weight", p + "downsample.0.bias", d.cin, d.cout, 3, px << 2);
+        for (int i = 0; i < d.n; ++i) {
+            ResLayer r;
+            const std::string q = p + "residual_blocks." + std::to_string(i) + ".";
+            r.cin = (i != 0 || d.down) ? d.cout : d.cin;
+            r.cout = d.cout;
+            r.scale = h->raw(q + "scale", 1);
+            r.g1 = h->raw(q + "norm1.weight", r.cin);
+            r.b1 = h->raw(q + "norm1.bias", r.cin);
+            r.conv1 = h->conv(q + "conv1.weight", q + "conv1.bias", r.cin, r.cout, 3, px);
+            r.ada_row = row;
+            h->raw_at(q + "norm2.proj.1.weight", (int64_t)2 * r.cout * T, h->ada_w + (size_t)row * T);
+            h->raw_at(q + "norm2.proj.1.bias", 2 * r.cout, h->ada_b + row);
+            row += 2 * r.cout;
+            r.conv2 = h->conv(q + "conv2.weight", q + "conv2.bias", r.cout, r.cout, 3, px);
+            r.has_skip = r.cin != r.cout;
+            if (r.has_skip) r.skip = h->conv(q + "skip.weight", q + "skip.bias", r.cin, r.cout, 1, px);
+            st.res.push_back(r);
+        }
+        if (d.attn) {
+            const std::string q = p + "self_attn_block.";
+            st.at.C = d.cout;
+            st.at.scale = h->raw(q + "scale", 1);
+            st.at.gamma = h->raw(q + "norm.weight", d.cout);
+            st.at.beta = h->raw(q + "norm.bias", d.cout);
+            st.at.qkv = h->conv(q + "attn.in_proj_weight", q + "attn.in_proj_bias", d.cout, 3 * d.cout, 1, px);
+            st.at.proj = h->conv(q + "attn.out_proj.weight", q + "attn.out_proj.bias", d.cout, d.cout, 1, px);
+        }
+        if (d.up)  // upsample then conv at the finer resolution (efficient_unet.py:169-173)
+            st.uconv = h->conv(p + "upsample.1.weight", p + "upsample.1.bias", d.cout, d.cout, 3, px << 2);
+    }
+    h->out_conv = h->conv("out_conv.weight", "out_conv.bias", C0, c.out_channels, 3, px1);
+}
+
+// ---- workspace arena -------------------------------------------------------------------------
+struct Arena {
+    char* base;
+    size_t cap;
+    bool dry;
+    size_t peak = 0;
+    struct Blk { size_t off, size; bool used; };
+    std::vector<Blk> blks;
+    bool overflow = false;
+
+    void* alloc(size_t bytes) {
+        bytes = align_up(bytes ? bytes : 1);
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (!blks[i].used && blks[i].size >= bytes) {
+                if (blks[i].size > bytes) {
+                    Blk rest{blks[i].off + bytes, blks[i].size - bytes, false};
+                    blks[i].size = bytes;
+                    blks.insert(blks.begin() + i + 1, rest);
+                }
+                blks[i].used = true;
+                return base + blks[i].off;
+            }
+        }
+        size_t end = blks.empty() ? 0 : blks.back().off + blks.back().size;
+        if (!blks.empty() && !blks.back().used) {  // grow the trailing free block
+            end = blks.back().off;
+            blks.pop_back();
+        }
+        blks.push_back({end, bytes, true});
+        if (end + bytes > peak) peak = end + bytes;
+        if (!dry && end + bytes > cap) overflow = true;
+        return base + end;
+    }
+    void release(const void* p) {
+        const size_t off = (const char*)p - base;
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (blks[i].off == off && blks[i].used) {
+                blks[i].used = false;
+                if (i + 1 < blks.size() && !blks[i + 1].used) {
+                    blks[i].size += blks[i + 1].size;
+                    blks.erase(blks.begin() + i + 1);
+                }
+                if (i > 0 && !blks[i - 1].used) {
+                    blks[i - 1].size += blks[i].size;
+                    blks.erase(blks.begin() + i);
+                }
+                return;
+            }
+        }
+    }
+};
+
+struct Tensor {
+    float* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    long bs() const { return (long)C * H * W; }
+    size_t bytes(int B) const { return (size_t)B * C * H * W * sizeof(float); }
+};
+
+inline Src src1(const Tensor& t) { return Src{t.p, nullptr, t.C, 0, t.bs(), 0}; }
+inline Src src2(const Tensor& a, const Tensor& b) { return Src{a.p, b.p, a.C, b.C, a.bs(), b.bs()}; }
+
+struct Ctx {
+    r2dm_handle* h;
+    Arena* ar;
+    hipStream_t st;
+    int B;
+    const float* proj;  // [B][ada_rows]
+    double* gn_partial;
+    hipError_t err = hipSuccess;
+    const char* where = "";
+
+    bool dry() const { return ar->dry; }
+    void note(hipError_t e, const char* w) {
+        if (e != hipSuccess && err == hipSuccess) {
+            err = e;
+            where = w;
+        }
+    }
+    const float* blob(size_t off) const { return h->blob + off; }
+
+    Tensor make(int C, int H, int W) {
+        Tensor t;
+        t.C = C;
+        t.H = H;
+        t.W = W;
+        t.p = (float*)ar->alloc(t.bytes(B));
+        return t;
+    }
+    void drop(const Tensor& t) { ar->release(t.p); }
+
+    float2* group_norm(const Src& x, int H, int W, const float* gamma, const float* beta, const float* ada) {
+        const int C = x.c0 + x.c1;
+        float2* aff = (float2*)ar->alloc((size_t)B * C * sizeof(float2));
+        if (!dry()) {
+            GNParams g{x, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows,
+                       gn_partial, aff, nullptr};
+            note(launch_group_norm(g, st), "group_norm");
+        }
+        return aff;
+    }
+
+    Tensor conv(const ConvLayer& L, const Src& x, int H, int W, int pro, const float2* aff, const Tensor* res,
+                size_t scale_off, bool has_scale, float* dst = nullptr) {
+        Tensor y;
+        y.C = L.cout;
+        y.H = H;
+        y.W = W;
+        y.p = dst ? dst : (float*)ar->alloc(y.bytes(B));
+        if (!dry()) {
+            ConvParams p;
+            p.x = x;
+            p.w = blob(L.w);
+            p.bias = blob(L.b);
+            p.aff = aff;
+            p.res = res ? res->p : nullptr;
+            p.res_bs = res ? res->bs() : 0;
+            p.scale = has_scale ? blob(scale_off) : nullptr;
+            p.y = y.p;
+            p.y_bs = y.bs();
+            p.B = B;
+            p.H = H;
+            p.W = W;
+            p.Cin = L.cin;
+            p.CinPad = L.cin_pad;
+            p.Cout = L.cout;
+            p.taps = L.taps;
+            p.co_tile = L.co_tile;
+            p.prologue = pro;
+            note(launch_conv(p, st), "conv");
+        }
+        return y;
+    }
+
+    // efficient_unet.py:95-110
+    Tensor residual_block(const ResLayer& r, const Src& x, int H, int W) {
+        float2* a1 = group_norm(x, H, W, blob(r.g1), blob(r.b1), nullptr);
+        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, a1, nullptr, 0, false);
+        ar->release(a1);
+        float2* a2 = group_norm(src1(t1), H, W, nullptr, nullptr, proj + r.ada_row);
+        Tensor skip;
+        const Tensor* res;
+        Tensor ident;
+        if (r.has_skip) {
+            skip = conv(r.skip, x, H, W, PRO_NONE, nullptr, nullptr, 0, false);
+            res = &skip;
+        } else {
+            ident.p = const_cast<float*>(x.p0);  // identity skip: block input is single-source here
+            ident.C = x.c0;
+            ident.H = H;
+            ident.W = W;
+            res = &ident;
+        }
+        Tensor out = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, a2, res, r.scale, true);
+        ar->release(a2);
+        drop(t1);
+        if (r.has_skip) drop(skip);
+        return out;
+    }
+
+    // efficient_unet.py:42-53
+    Tensor attention_block(const AttnLayer& a, const Tensor& x) {
+        float2* aff = group_norm(src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
+        Tensor qkv = conv(a.qkv, src1(x), x.H, x.W, PRO_AFFINE, aff, nullptr, 0, false);
+        ar->release(aff);
+        Tensor o = make(a.C, x.H, x.W);
+        if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st), "attention");
+        drop(qkv);
+        Tensor out = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true);
+        drop(o);
+        return out;
+    }
+
+    // efficient_unet.py:178-185.  Never frees `in`; returns a fresh tensor.
+    Tensor stage(const Stage& s, const Src& in, int H, int W) {
+        Tensor cur;
+        bool have = false;
+        if (s.down) {
+            Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false);
+            cur = make(s.cout, H / 2, W / 2);
+            if (!dry()) note(launch_fir_down2(t.p, t.bs(), cur.p, cur.bs(), B, s.cout, H, W, st), "fir_down2");
+            drop(t);
+            H /= 2;
+            W /= 2;
+            have = true;
+        }
+        for (const ResLayer& r : s.res) {
+            Tensor nxt = residual_block(r, have ? src1(cur) : in, H, W);
+            if (have) drop(cur);
+            cur = nxt;
+            have = true;
+        }
+        if (s.attn) {
+            Tensor nxt = attention_block(s.at, cur);
+            drop(cur);
+            cur = nxt;
+        }
+        if (s.up) {
+            Tensor u = make(s.cout, 2 * H, 2 * W);
+            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st), "fir_up2");
+            drop(cur);
+            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false);
+            drop(u);
+        }
+        return cur;
+    }
+};
+
+int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, float* out, int B, hipStream_t st) {
+    const r2dm_config& c = h->cfg;
+    Ctx k{h, &ar, st, B, nullptr, nullptr};
+    const int H = c.height, W = c.width, T = c.temb_channels;
+    float* act = (float*)ar.alloc((size_t)B * T * sizeof(float));
+    float* proj = (float*)ar.alloc((size_t)B * h->ada_rows * sizeof(float));
+    k.gn_partial = (double*)ar.alloc((size_t)B * c.gn_num_groups * 256 * 2 * sizeof(double));
+    k.proj = proj;
+    if (!k.dry()) {
+        EmbedParams e{cond, k.blob(h->freqs), k.blob(h->w1), k.blob(h->b1), k.blob(h->w2), k.blob(h->b2), act, B,
+                      c.base_channels, T};
+        k.note(launch_time_embedding(e, st), "time_embedding");
+        k.note(launch_ada_proj(act, k.blob(h->ada_w), k.blob(h->ada_b), proj, B, T, h->ada_rows, st), "ada_proj");
+    }
+    // input = cat([x, cenc]) without materialising it (efficient_unet.py:278-281)
+    Src in{x, c.coord_channels ? k.blob(h->cenc) : nullptr, c.in_channels, c.coord_channels,
+           (long)c.in_channels * H * W, 0};
+    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false);
+    Tensor h1 = k.stage(h->stages[0], src1(h0), H, W);
+    k.drop(h0);
+    Tensor h2 = k.stage(h->stages[1], src1(h1), H, W);
+    Tensor h3 = k.stage(h->stages[2], src1(h2), H / 2, W / 2);
+    Tensor h4 = k.stage(h->stages[3], src1(h3), H / 4, W / 4);
+    Tensor u = k.stage(h->stages[4], src1(h4), H / 8, W / 8);
+    k.drop(h4);
+    Tensor u3 = k.stage(h->stages[5], src2(u, h3), H / 4, W / 4);
+    k.drop(u);
+    k.drop(h3);
+    Tensor u2 = k.stage(h->stages[6], src2(u3, h2), H / 2, W / 2);
+    k.drop(u3);
+    k.drop(h2);
+    Tensor u1 = k.stage(h->stages[7], src2(u2, h1), H, W);
+    k.drop(u2);
+    k.drop(h1);
+    k.conv(h->out_conv, src1(u1), H, W, PRO_NONE, nullptr, nullptr, 0, false, out);
+    k.drop(u1);
+    ar.release(act);
+    ar.release(proj);
+    ar.release(k.gn_partial);
+    if (k.err != hipSuccess) return fail(2, "kernel launch failed in %s: %s", k.where, hipGetErrorString(k.err));
+    if (ar.overflow) return fail(3, "workspace too small: need %zu bytes", ar.peak);
+    return 0;
+}
+
+int check_config(const r2dm_config& c) {
+    if (c.in_channels < 1 || c.out_channels < 1 || c.height < 8 || c.width < 32) return fail(1, "bad image geometry");
+    if ((c.height % 8) || (c.width % 32)) return fail(1, "height must be a multiple of 8 and width of 32 (3 FIR levels, 16-byte rows)");
+    if (c.base_channels % 2 || c.base_channels < 4) return fail(1, "base_channels must be even");
+    if (c.gn_num_groups < 1 || c.max_batch < 1) return fail(1, "bad gn_num_groups / max_batch");
+    int Cl[5] = {c.base_channels, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        if (c.channel_multiplier[i] < 1 || c.num_residual_blocks[i] < 1) return fail(1, "bad multiplier / block count");
+        Cl[i + 1] = c.base_channels * c.channel_multiplier[i];
+    }
+    for (int i = 0; i < 5; ++i)
+        if (Cl[i] % c.gn_num_groups) return fail(1, "channels %d not divisible by %d groups", Cl[i], c.gn_num_groups);
+    for (int i = 1; i <= 3; ++i)  // concat seam must fall on a group boundary: 2*C / G divides C
+        if (Cl[i] % (2 * Cl[i] / c.gn_num_groups)) return fail(1, "GroupNorm group straddles the skip concat");
+    const int N = (c.height / 8) * (c.width / 8);
+    if (!attention_supported(Cl[4], c.attn_num_heads, N) || !attention_supported(Cl[3], c.attn_num_heads, N))
+        return fail(1, "attention: head_dim must be 32 or 64 and tokens a multiple of 32 (got C=%d/%d, heads=%d, N=%d)",
+                    Cl[4], Cl[3], c.attn_num_heads, N);
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* r2dm_last_error(void) { return g_err; }
+const char* r2dm_version(void) { return "r2dm_hip 0.1 (gfx950)"; }
+
+int r2dm_create(r2dm_handle** out, const r2dm_config* cfg) {
+    if (!out || !cfg) return fail(1, "null argument");
+    if (int rc = check_config(*cfg)) return rc;
+    r2dm_handle* h = new r2dm_handle();
+    h->cfg = *cfg;
+    (void)hipGetDevice(&h->device);
+    build_plan(h);
+    *out = h;
+    return 0;
+}
+
+void r2dm_destroy(r2dm_handle* h) { delete h; }
+
+int64_t r2dm_num_tensors(const r2dm_handle* h) { return h ? (int64_t)h->slots.size() : 0; }
+
+int r2dm_tensor_at(const r2dm_handle* h, int64_t i, r2dm_tensor_info* out) {
+    if (!h || !out || i < 0 || i >= (int64_t)h->slots.size()) return fail(1, "tensor index out of range");
+    out->key = h->slots[i].key.c_str();
+    out->numel = h->slots[i].numel;
+    return 0;
+}
+
+size_t r2dm_blob_bytes(const r2dm_handle* h) { return h ? h->blob_floats * sizeof(float) : 0; }
+
+int r2dm_bind_blob(r2dm_handle* h, void* blob, size_t bytes) {
+    if (!h || !blob) return fail(1, "null argument");
+    if (bytes < r2dm_blob_bytes(h)) return fail(1, "blob too small: %zu < %zu", bytes, r2dm_blob_bytes(h));
+    if ((uintptr_t)blob & (kAlign - 1)) return fail(1, "blob must be %zu-byte aligned", kAlign);
+    h->blob = (float*)blob;
+    return 0;
+}
+
+int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel, void* stream) {
+    if (!h || !src) return fail(1, "null argument");
+    if (!h->blob) return fail(1, "bind a blob first");
+    if (i < 0 || i >= (int64_t)h->slots.size()) return fail(1, "tensor index out of range");
+    const Slot& s = h->slots[i];
+    if (numel != s.numel) return fail(1, "%s: expected %lld elements, got %lld", s.key.c_str(), (long long)s.numel, (long long)numel);
+    hipStream_t st = (hipStream_t)stream;
+    if (s.kind == SLOT_RAW) {
+        HIP_TRY(hipMemcpyAsync(h->blob + s.off, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIP_TRY(launch_pack_conv(src, h->blob + s.off, s.conv.cout, s.conv.cin, s.conv.taps, s.conv.co_tile,
+                                 s.conv.cin_pad, st));
+    }
+    return 0;
+}
+
+size_t r2dm_workspace_bytes(const r2dm_handle* hc, int32_t B) {
+    r2dm_handle* h = const_cast<r2dm_handle*>(hc);
+    if (!h || B < 1) return 0;
+    auto it = h->ws_cache.find(B);
+    if (it != h->ws_cache.end()) return it->second;
+    Arena ar{(char*)kAlign, 0, true};
+    run_forward(h, ar, (const float*)kAlign, (const float*)kAlign, (float*)kAlign, B, nullptr);
+    const size_t bytes = ar.peak + kAlign;
+    h->ws_cache[B] = bytes;
+    return bytes;
+}
+
+int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t B, void* ws,
+                      size_t ws_bytes, void* stream) {
+    if (!h || !x || !cond || !out || !ws) return fail(1, "null argument");
+    if (!h->blob) return fail(1, "weights not loaded (r2dm_bind_blob / r2dm_load_tensor)");
+    if (B < 1) return fail(1, "batch must be >= 1");
+    char* base = (char*)align_up((size_t)(uintptr_t)ws);
+    const size_t cap = ws_bytes - (size_t)(base - (char*)ws);
+    Arena ar{base, cap, false};
+    return run_forward(h, ar, x, cond, out, B, (hipStream_t)stream);
+}
+
+int r2dm_posterior_step(const float* x_t, const float* pred, const float* noise, const float* coef, float* x_s,
+                        int32_t B, int64_t per_sample, int32_t mode, int32_t objective, float clip, void* stream) {
+    if (!x_t || !pred || !coef || !x_s) return fail(1, "null argument");
+    PosteriorParams p{x_t, pred, noise, coef, x_s, B, per_sample, mode, objective, clip};
+    HIP_TRY(launch_posterior(p, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t B, int32_t H, int32_t W,
+                           float min_depth, float max_depth, void* stream) {
+    if (!x || !ang || !out) return fail(1, "null argument");
+    HIP_TRY(launch_lidar_postprocess(x, ang, out, B, H, W, min_depth, max_depth, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- single-kernel entry points (unit parity tests) ---------------------------------------------
+int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t B, int32_t H, int32_t W) {
+    const int taps = ksize * ksize;
+    const int ct = conv_pick_co_tile(cout, taps, (long)B * H * W);
+    return (int64_t)((cout + ct - 1) / ct) * conv_cin_pad(cin, taps, ct) * taps * ct;
+}
+
+int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w_packed, const float* aff,
+                     int32_t prologue, const float* residual, const float* scale, float* y, int32_t B, int32_t cin,
+                     int32_t cout, int32_t H, int32_t W, int32_t ksize, void* stream) {
+    if (!x || !w || !bias || !w_packed || !y) return fail(1, "null argument");
+    if (ksize != 1 && ksize != 3) return fail(1, "kernel size must be 1 or 3");
+    hipStream_t st = (hipStream_t)stream;
+    ConvParams p;
+    p.taps = ksize * ksize;
+    p.co_tile = conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    p.CinPad = conv_cin_pad(cin, p.taps, p.co_tile);
+    HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st));
+    p.x = Src{x, nullptr, cin, 0, (long)cin * H * W, 0};
+    p.w = w_packed;
+    p.bias = bias;
+    p.aff = (const float2*)aff;
+    p.res = residual;
+    p.res_bs = (long)cout * H * W;
+    p.scale = scale;
+    p.y = y;
+    p.y_bs = (long)cout * H * W;
+    p.B = B;
+    p.H = H;
+    p.W = W;
+    p.Cin = cin;
+    p.Cout = cout;
+    p.prologue = prologue;
+    HIP_TRY(launch_conv(p, st));
+    return 0;
+}
+
+size_t r2dm_group_norm_scratch_bytes(int32_t B, int32_t groups) { return (size_t)B * groups * 256 * 2 * sizeof(double); }
+
+int r2dm_group_norm_affine(const float* x, const float* gamma, const float* beta, const float* ada, void* scratch,
+                           float* aff, float* stats, int32_t B, int32_t C, int32_t H, int32_t W, int32_t groups,
+                           float eps, void* stream) {
+    if (!x || !scratch || !aff) return fail(1, "null argument");
+    GNParams g{Src{x, nullptr, C, 0, (long)C * H * W, 0}, B, H, W, groups, eps, gamma, beta, ada, 2L * C,
+               (double*)scratch, (float2*)aff, stats};
+    HIP_TRY(launch_group_norm(g, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_affine_act(const float* x, const float* aff, float* y, int32_t B, int32_t C, int64_t hw, int32_t silu,
+                    void* stream) {
+    HIP_TRY(launch_gn_apply(x, (const float2*)aff, y, B, C, hw, silu, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_fir_down2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_fir_up2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    HIP_TRY(launch_fir_up2(x, (long)C * H * W, y, (long)C * H * W * 4, B, C, H, W, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_attention(const float* qkv, float* out, int32_t B, int32_t C, int32_t heads, int32_t N, void* stream) {
+    if (!attention_supported(C, heads, N)) return fail(1, "attention: unsupported shape C=%d heads=%d N=%d", C, heads, N);
+    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_time_embedding(const float* cond, const float* freqs, const float* w1, const float* b1, const float* w2,
+                        const float* b2, float* act, int32_t B, int32_t base, int32_t T, void* stream) {
+    EmbedParams e{cond, freqs, w1, b1, w2, b2, act, B, base, T};
+    HIP_TRY(launch_time_embedding(e, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

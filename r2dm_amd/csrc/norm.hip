@@ -1,0 +1,159 @@
+// K4 / K5: GroupNorm statistics and the folded per-(sample, channel) affine.
+//
+// Reference: nn.GroupNorm(8, C, eps=1e-6) (/root/reference/models/efficient_unet.py:33,72) and AdaGN
+// (/root/reference/models/ops.py:176-200).  Both are folded to  y = x * a + d  with
+//     GroupNorm : a = rstd * gamma[c]            d = beta[c]     - mean * a
+//     AdaGN     : a = rstd * (1 + scale[b,c])    d = shift[b,c]  - mean * a
+// (the same scale/bias form ATen's GroupNorm kernels apply).  The apply itself is fused into the
+// consuming convolution's load stage (conv_mfma.hip); gn_apply_kernel below exists for unit tests
+// and for callers that need the normalised tensor.
+//
+// Statistics: HBM-bound single pass over the tensor, 16-byte loads, fp64 sum / sum-of-squares
+// (fp64 VALU is not a bottleneck on a streaming kernel and makes E[x^2]-E[x]^2 safe for groups of
+// up to 2^22 elements), wavefront shuffle reduce, fixed-order cross-block combine => deterministic.
+#include "common.h"
+
+namespace r2dm {
+
+constexpr int kGnThreads = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// grid = (splits, G, B).  Group g of sample b = cpg consecutive planes (all inside one of the two
+// sources), i.e. n = cpg*HW contiguous floats; split s reduces elements [s*len, (s+1)*len).
+__global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(Src x, int cpg, long hw, int splits,
+                                                                double* __restrict__ partial) {
+    const int s = blockIdx.x, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
+    const long n = (long)cpg * hw;
+    const float* base = x.plane(b, g * cpg, hw);
+    long len = (n + splits - 1) / splits;
+    len = (len + 3) & ~3L;
+    const long lo = s * len, hi = lo + len < n ? lo + len : n;
+    double sum = 0.0, sq = 0.0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && ((n & 3) == 0);
+    if (vec) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(base);
+        for (long i = lo / 4 + threadIdx.x; i < hi / 4; i += kGnThreads) {
+            const f32x4 v = p4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (double)v[j];
+                sum += d;
+                sq = fma(d, d, sq);
+            }
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kGnThreads) {
+            const float v = base[i];
+            sum += (double)v;
+            sq += (double)v * (double)v;
+        }
+    }
+    __shared__ double red[2][kGnThreads / 64];
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sum;
+        red[1][threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, q = 0.0;
+        for (int w = 0; w < kGnThreads / 64; ++w) {
+            a += red[0][w];
+            q += red[1][w];
+        }
+        double* o = partial + (((long)b * G + g) * splits + s) * 2;
+        o[0] = a;
+        o[1] = q;
+    }
+}
+
+// grid = (G, B), one wave: combine the splits in index order, then emit (a, d) for the group's channels.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restrict__ partial, int splits, int C,
+                                                         int cpg, long hw, float eps,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ ada, long ada_stride,
+                                                         float2* __restrict__ aff, float* __restrict__ stats) {
+    const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x;
+    const double* p = partial + ((long)b * G + g) * splits * 2;
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < splits; ++s) {
+        sum += p[2 * s];
+        sq += p[2 * s + 1];
+    }
+    const double n = (double)cpg * (double)hw;
+    const double mean_d = sum / n;
+    double var_d = sq / n - mean_d * mean_d;
+    var_d = var_d > 0.0 ? var_d : 0.0;
+    const float mean = (float)mean_d;
+    const float rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    if (stats && threadIdx.x == 0) {
+        stats[((long)b * G + g) * 2 + 0] = mean;
+        stats[((long)b * G + g) * 2 + 1] = rstd;
+    }
+    for (int i = threadIdx.x; i < cpg; i += 64) {
+        const int c = g * cpg + i;
+        float w, sh;
+        if (ada) {
+            w = 1.0f + ada[b * ada_stride + c];
+            sh = ada[b * ada_stride + C + c];
+        } else {
+            w = gamma ? gamma[c] : 1.0f;
+            sh = beta ? beta[c] : 0.0f;
+        }
+        const float a = rstd * w;
+        aff[(long)b * C + c] = make_float2(a, sh - mean * a);
+    }
+}
+
+int gn_splits(int B, int groups, long group_elems) {
+    // aim at >= ~2048 blocks chip-wide but keep >= 16 KiB per block
+    long want = 2048 / ((long)B * groups > 0 ? (long)B * groups : 1);
+    long cap = group_elems / 4096;
+    long s = want < cap ? want : cap;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+hipError_t launch_group_norm(const GNParams& p, hipStream_t st) {
+    const int C = p.x.channels();
+    if (C % p.groups) return hipErrorInvalidValue;
+    const int cpg = C / p.groups;
+    if (p.x.c1 > 0 && (p.x.c0 % cpg)) return hipErrorInvalidValue;  // a group may not straddle the concat seam
+    const long hw = (long)p.H * p.W;
+    const int splits = gn_splits(p.B, p.groups, cpg * hw);
+    gn_partial_kernel<<<dim3(splits, p.groups, p.B), kGnThreads, 0, st>>>(p.x, cpg, hw, splits, p.partial);
+    gn_finalize_kernel<<<dim3(p.groups, p.B), 64, 0, st>>>(p.partial, splits, C, cpg, hw, p.eps, p.gamma, p.beta,
+                                                            p.ada, p.ada_stride, p.aff, p.stats);
+    return hipGetLastError();
+}
+
+// y = f(x*a+d), one (b,c) plane per blockIdx.y -- test / utility path only
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float2* __restrict__ aff,
+                                                       float* __restrict__ y, long hw, int silu) {
+    const long plane = blockIdx.y;
+    const float2 ad = aff[plane];
+    const float* xp = x + plane * hw;
+    float* yp = y + plane * hw;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        float v = xp[i] * ad.x + ad.y;
+        yp[i] = silu ? silu_f(v) : v;
+    }
+}
+
+hipError_t launch_gn_apply(const float* x, const float2* aff, float* y, int B, int C, long hw, int silu,
+                           hipStream_t st) {
+    int bx = (int)((hw + 255) / 256);
+    if (bx > 64) bx = 64;
+    gn_apply_kernel<<<dim3(bx, B * C), 256, 0, st>>>(x, aff, y, hw, silu);
+    return hipGetLastError();
+}
+
+}  // namespace r2dm

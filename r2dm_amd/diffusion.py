@@ -1,0 +1,418 @@
+"""Reverse-process samplers with the reference's API surface.
+
+Mirrors (names, arguments, draw order, error behaviour):
+  /root/reference/models/diffusion/base.py:8-163            GaussianDiffusion
+  /root/reference/models/diffusion/continuous_time.py:66-317 ContinuousTimeGaussianDiffusion
+  /root/reference/models/diffusion/discrete_time.py:51-201   DiscreteTimeGaussianDiffusion
+
+MI355X design, not a translation:
+  * All per-step schedule scalars (log-SNR, alpha, sigma, c, ...) are evaluated once, on the
+    host, with the same float32 torch ops the reference uses, and uploaded as one table; the
+    step loop itself launches no scalar kernels and never synchronises.
+  * The posterior update ``x_t, prediction, noise -> x_s`` is ONE fused HIP kernel
+    (``r2dm_posterior_step``) that replays the reference's float32 operation order with FMA
+    contraction off.
+  * Noise stays in ``torch.randn(generator=...)`` so that seeds mean what they mean in the
+    reference (base.py:71-94).
+
+Training-side members (loss, timestep sampling) are out of scope.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import List, Literal, Optional
+
+import torch
+from torch import nn
+from torch.special import expm1
+
+from . import _lib
+
+try:  # progress bars are optional
+    from tqdm.auto import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(it, **_):
+        return it
+
+_OBJECTIVES = {"eps": 0, "v": 1, "x_0": 2}
+# posterior kernel modes (csrc/posterior.hip)
+_M_CT_DDPM, _M_CT_DDIM, _M_DT_DDPM, _M_DT_DDIM, _M_DT_DDIM_NOISE = 0, 1, 2, 3, 4
+_NCOEF = 8
+
+
+# --------------------------------------------------------------------------------------
+# log-SNR schedules (continuous_time.py:14-63).  Evaluated on the HOST in float32.
+# --------------------------------------------------------------------------------------
+def _log(t: torch.Tensor, eps: float = 1e-20) -> torch.Tensor:
+    return torch.log(t.clamp(min=eps))
+
+
+def log_snr_linear(t):
+    return -_log(expm1(1e-4 + 10 * (t**2)))
+
+
+def log_snr_cosine(t, logsnr_min: float = -15, logsnr_max: float = 15):
+    t_min = math.atan(math.exp(-0.5 * logsnr_max))
+    t_max = math.atan(math.exp(-0.5 * logsnr_min))
+    return -2 * _log(torch.tan(t_min + t * (t_max - t_min)))
+
+
+def log_snr_cosine_shifted(t, image_d, noise_d, logsnr_min: float = -15, logsnr_max: float = 15):
+    return log_snr_cosine(t, logsnr_min, logsnr_max) + 2 * math.log(noise_d / image_d)
+
+
+def log_snr_cosine_interpolated(t, image_d, noise_d_low, noise_d_high, logsnr_min: float = -15,
+                                logsnr_max: float = 15):
+    low = log_snr_cosine_shifted(t, image_d, noise_d_low, logsnr_min, logsnr_max)
+    high = log_snr_cosine_shifted(t, image_d, noise_d_high, logsnr_min, logsnr_max)
+    return t * low + (1 - t) * high
+
+
+def log_snr_to_alpha_sigma(log_snr):
+    return log_snr.sigmoid().sqrt(), (-log_snr).sigmoid().sqrt()
+
+
+def discrete_tables(num_training_steps: int, schedule: str):
+    """beta / alpha_bar / alpha_bar_prev / snr in float64 -> float32 (discrete_time.py:12-78)."""
+    T = num_training_steps
+    if schedule == "linear":
+        s = 1000 / T
+        beta = torch.linspace(s * 0.0001, s * 0.02, T, dtype=torch.float64)
+    elif schedule in ("cosine", "sigmoid"):
+        t = torch.linspace(0, T, T + 1, dtype=torch.float64) / T
+        if schedule == "cosine":
+            ab = torch.cos((t + 0.008) / (1 + 0.008) * math.pi * 0.5) ** 2
+        else:
+            start, end, tau = -3, 3, 1
+            v0, v1 = torch.tensor(start / tau).sigmoid(), torch.tensor(end / tau).sigmoid()
+            ab = (-((t * (end - start) + start) / tau).sigmoid() + v1) / (v1 - v0)
+        ab = ab / ab[0]
+        beta = torch.clip(1 - (ab[1:] / ab[:-1]), 0, 0.999)
+    else:
+        raise ValueError(f"invalid beta schedule {schedule}")
+    alpha_bar = torch.cumprod(1 - beta, dim=0)
+    alpha_bar_prev = torch.cat([alpha_bar.new_ones(1), alpha_bar[:-1]])
+    snr = alpha_bar / (1 - alpha_bar)
+    return beta.float(), alpha_bar.float(), alpha_bar_prev.float(), snr.float()
+
+
+# --------------------------------------------------------------------------------------
+class GaussianDiffusion(nn.Module):
+    """Common state and RNG plumbing (base.py:8-163)."""
+
+    def __init__(
+        self,
+        model: nn.Module,
+        sampling: Literal["ddpm", "ddim"] = "ddpm",
+        prediction_type: Literal["eps", "v", "x_0"] = "eps",
+        loss_type="l2",
+        num_training_steps: Optional[int] = 1000,
+        noise_schedule: str = "linear",
+        min_snr_loss_weight: bool = True,
+        min_snr_gamma: float = 5.0,
+        sampling_resolution: Optional[tuple] = None,
+        clip_sample: bool = True,
+        clip_sample_range: float = 1,
+    ):
+        super().__init__()
+        self.model = model
+        self.sampling = sampling
+        self.num_training_steps = num_training_steps
+        self.objective = prediction_type
+        self.noise_schedule = noise_schedule
+        self.loss_type = loss_type
+        self.min_snr_loss_weight = min_snr_loss_weight
+        self.min_snr_gamma = min_snr_gamma
+        self.clip_sample = clip_sample
+        self.clip_sample_range = clip_sample_range
+        if sampling_resolution is None:
+            assert hasattr(self.model, "resolution")
+            assert hasattr(self.model, "in_channels")
+            self.sampling_shape = (self.model.in_channels, *self.model.resolution)
+        else:
+            assert len(sampling_resolution) == 2
+            assert hasattr(self.model, "in_channels")
+            self.sampling_shape = (self.model.in_channels, *sampling_resolution)
+        self.setup_parameters()
+        self.register_buffer("_dummy", torch.tensor([]))
+
+    @property
+    def device(self):
+        return self._dummy.device
+
+    # -- RNG: identical draw shapes / order to base.py:71-94 -------------------------------
+    def randn(self, *shape, rng: List[torch.Generator] | torch.Generator | None = None, **kwargs):
+        if rng is None:
+            return torch.randn(*shape, **kwargs)
+        elif isinstance(rng, torch.Generator):
+            return torch.randn(*shape, generator=rng, **kwargs)
+        elif isinstance(rng, list):
+            assert len(rng) == shape[0]
+            return torch.stack([torch.randn(*shape[1:], generator=r, **kwargs) for r in rng])
+        else:
+            raise ValueError(f"invalid rng: {rng}")
+
+    def randn_like(self, x, rng=None):
+        return self.randn(*x.shape, rng=rng, device=x.device, dtype=x.dtype)
+
+    def setup_parameters(self) -> None:
+        raise NotImplementedError
+
+    # -- training side: out of scope ------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            "r2dm_amd builds the sampling path only; the training loss "
+            "(reference base.py:122-149) is out of scope -- see DESIGN.md")
+
+    p_loss = forward
+
+    def _objective_id(self) -> int:
+        if self.objective not in _OBJECTIVES:
+            raise ValueError(f"invalid objective {self.objective}")
+        return _OBJECTIVES[self.objective]
+
+    def _clip(self) -> float:
+        return float(self.clip_sample_range) if self.clip_sample else -1.0
+
+    def _posterior(self, x_t, pred, noise, coef, mode_id: int):
+        """x_s = posterior(x_t, prediction, noise) in one HIP launch."""
+        return _lib.posterior_step(x_t, pred, noise, coef, mode_id, self._objective_id(), self._clip())
+
+
+# --------------------------------------------------------------------------------------
+class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
+    """Variational-diffusion-style continuous-time process (continuous_time.py:66-317)."""
+
+    def __init__(
+        self,
+        model: nn.Module,
+        prediction_type: Literal["eps", "v", "x_0"] = "eps",
+        loss_type="l2",
+        noise_schedule: Literal["linear", "cosine", "cosine_shifted", "cosine_interpolated"] = "cosine",
+        min_snr_loss_weight: bool = True,
+        min_snr_gamma: float = 5.0,
+        sampling_resolution: Optional[tuple] = None,
+        clip_sample: bool = True,
+        clip_sample_range: float = 1,
+        image_d: float = None,
+        noise_d_low: float = None,
+        noise_d_high: float = None,
+    ):
+        self.image_d, self.noise_d_low, self.noise_d_high = image_d, noise_d_low, noise_d_high
+        super().__init__(
+            model=model,
+            sampling="ddpm",
+            prediction_type=prediction_type,
+            loss_type=loss_type,
+            num_training_steps=None,
+            noise_schedule=noise_schedule,
+            min_snr_loss_weight=min_snr_loss_weight,
+            min_snr_gamma=min_snr_gamma,
+            sampling_resolution=sampling_resolution,
+            clip_sample=clip_sample,
+            clip_sample_range=clip_sample_range,
+        )
+
+    def setup_parameters(self) -> None:
+        if self.noise_schedule == "linear":
+            f = log_snr_linear
+        elif self.noise_schedule == "cosine":
+            f = log_snr_cosine
+        elif self.noise_schedule == "cosine_shifted":
+            assert self.image_d is not None and self.noise_d_low is not None
+            f = partial(log_snr_cosine_shifted, image_d=self.image_d, noise_d=self.noise_d_low)
+        elif self.noise_schedule == "cosine_interpolated":
+            assert self.image_d is not None and self.noise_d_low is not None and self.noise_d_high is not None
+            f = partial(log_snr_cosine_interpolated, image_d=self.image_d, noise_d_low=self.noise_d_low,
+                        noise_d_high=self.noise_d_high)
+        else:
+            raise ValueError(f"invalid beta schedule: {self.noise_schedule}")
+        self._log_snr_1d = f
+
+    def log_snr(self, t: torch.Tensor) -> torch.Tensor:
+        """(B,) -> (B,1,1,1), as continuous_time.py:14-29."""
+        return self._log_snr_1d(t)[:, None, None, None]
+
+    def get_network_condition(self, steps):
+        return self._log_snr_1d(steps)
+
+    # -- host-side coefficient table -------------------------------------------------------
+    def _coefficients(self, step_t: torch.Tensor, step_s: torch.Tensor, mode: str, ddim_eta: float):
+        """Per-row scalars of continuous_time.py:203-229, float32 on the host.
+        Returns (cond (N,), coef (N,8), kernel mode)."""
+        step_t = step_t.detach().to("cpu", torch.float32)
+        step_s = step_s.detach().to("cpu", torch.float32)
+        lt, ls = self._log_snr_1d(step_t), self._log_snr_1d(step_s)
+        a_t, s_t = log_snr_to_alpha_sigma(lt)
+        a_s, s_s = log_snr_to_alpha_sigma(ls)
+        z = torch.zeros_like(lt)
+        if mode == "ddpm":
+            c = -expm1(lt - ls)
+            coef = torch.stack([a_t, s_t, a_s, s_s, c, s_s * c.sqrt(), z, z], dim=-1)
+            mode_id = _M_CT_DDPM
+        elif mode == "ddim":
+            c_1 = ddim_eta * s_s / s_t * (1 - a_t**2 / a_s**2).sqrt()
+            c_2 = (1 - a_s**2 - c_1**2).sqrt()
+            coef = torch.stack([a_t, s_t, a_s, s_s, z, z, c_1, c_2], dim=-1)
+            mode_id = _M_CT_DDIM
+        else:
+            raise ValueError(f"invalid mode {mode}")
+        return lt, coef.contiguous(), mode_id
+
+    @torch.inference_mode()
+    def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",
+               ddim_eta: float = 0.0):
+        """One reverse step p(z_s | z_t), 0 <= s < t <= 1 (continuous_time.py:192-232)."""
+        self._objective_id()
+        cond, coef, mode_id = self._coefficients(step_t, step_s, mode, ddim_eta)
+        dev = x_t.device
+        prediction = self.model(x_t, cond.to(dev))
+        noise = self.randn_like(x_t, rng=rng)
+        return self._posterior(x_t, prediction, noise, coef.to(dev), mode_id)
+
+    @torch.inference_mode()
+    def sample(self, batch_size: int, num_steps: int, progress: bool = True, rng=None,
+               return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm", ddim_eta: float = 0.0):
+        """Ancestral / DDIM sampling from t=1 to t=0 (continuous_time.py:234-258)."""
+        dev = self.device
+        self._objective_id()
+        x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=dev)
+        if return_all:
+            out = [x]
+        steps = torch.linspace(1.0, 0.0, num_steps + 1)
+        cond, coef, mode_id = self._coefficients(steps[:-1], steps[1:], mode, ddim_eta)
+        cond = cond[:, None].expand(num_steps, batch_size).contiguous().to(dev)
+        coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
+        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+            prediction = self.model(x, cond[i])
+            noise = self.randn_like(x, rng=rng)
+            x = self._posterior(x, prediction, noise, coef[i], mode_id)
+            if return_all:
+                out.append(x)
+        return torch.stack(out) if return_all else x
+
+    # -- forward process pieces used by RePaint (continuous_time.py:169-190) ----------------
+    def q_step_from_x_0(self, x_0, step_t, rng=None):
+        noise = self.randn_like(x_0, rng=rng)
+        alpha, sigma = log_snr_to_alpha_sigma(self.log_snr(step_t.cpu().float()).to(x_0.device))
+        return x_0 * alpha + noise * sigma, noise
+
+    def q_step(self, x_s, step_t, step_s, rng=None):
+        lt = self.log_snr(step_t.cpu().float()).to(x_s.device)
+        ls = self.log_snr(step_s.cpu().float()).to(x_s.device)
+        a_t, s_t = log_snr_to_alpha_sigma(lt)
+        a_s, s_s = log_snr_to_alpha_sigma(ls)
+        a_ts = a_t / a_s
+        var_noise = self.randn_like(x_s, rng=rng)
+        var = s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)
+        return x_s * a_ts + var.sqrt() * var_noise
+
+    @torch.inference_mode()
+    def repaint(self, known, mask, num_steps: int, num_resample_steps: int = 1, jump_length: int = 1,
+                progress: bool = True, rng=None, return_all: bool = False):
+        """RePaint inpainting on top of the same p_step (continuous_time.py:260-317)."""
+        assert num_resample_steps > 0
+        assert jump_length > 0
+        B = known.shape[0]
+        dev = self.device
+        x_t = self.randn(B, *self.sampling_shape, rng=rng, device=dev)
+        steps = torch.linspace(1, 0, num_steps + 1)[None].repeat_interleave(B, dim=0)
+        if return_all:
+            out = [x_t]
+        for i in tqdm(range(num_steps), desc="RePaint", leave=False, disable=not progress):
+            for j in range(num_resample_steps):
+                t, s = steps[:, [i]], steps[:, [i + 1]]
+                r = t + torch.linspace(0, 1, jump_length + 1)[None] * (s - t)
+                x = x_t
+                for k in range(jump_length):
+                    known_s, _ = self.q_step_from_x_0(known, r[:, k + 1], rng=rng)
+                    unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng)
+                    x = mask * known_s + (1 - mask) * unknown_s
+                x_s = x
+                if return_all:
+                    out.append(x_s)
+                if (i == num_steps - 1) or (j == num_resample_steps - 1):
+                    x_t = x
+                    break
+                for k in range(jump_length, 0, -1):
+                    x = self.q_step(x, r[:, k - 1], r[:, k], rng=rng)
+                x_t = x
+        return torch.stack(out) if return_all else x_s
+
+
+# --------------------------------------------------------------------------------------
+class DiscreteTimeGaussianDiffusion(GaussianDiffusion):
+    """DDPM / DDIM over an integer-step beta schedule (discrete_time.py:51-201)."""
+
+    def setup_parameters(self) -> None:
+        assert self.num_training_steps is not None
+        beta, ab, abp, snr = discrete_tables(self.num_training_steps, self.noise_schedule)
+        v4 = lambda t: t[:, None, None, None]
+        self.register_buffer("beta", v4(beta))
+        self.register_buffer("alpha_bar", v4(ab))
+        self.register_buffer("alpha_bar_prev", v4(abp))
+        self.register_buffer("snr", v4(snr))
+
+    def get_network_condition(self, steps):
+        return steps
+
+    def _coefficients(self, steps: torch.Tensor, mode: str, eta: float):
+        """Row scalars of discrete_time.py:135-177 on the host (float32, same op order)."""
+        idx = steps.detach().to("cpu", torch.long)
+        beta = self.beta.detach().cpu()[idx, 0, 0, 0]
+        ab = self.alpha_bar.detach().cpu()[idx, 0, 0, 0]
+        abp = self.alpha_bar_prev.detach().cpu()[idx, 0, 0, 0]
+        alpha = 1 - beta
+        live = (idx != 0).float()  # var_noise[steps == 0] *= 0 (discrete_time.py:162,176)
+        if self.objective == "eps":
+            k0, k1 = ab.rsqrt(), (ab.reciprocal() - 1).sqrt()
+        elif self.objective == "v":
+            k0, k1 = ab.sqrt(), (1 - ab).sqrt()
+        else:
+            k0 = k1 = torch.zeros_like(ab)
+        if mode == "ddpm":
+            x0c = abp.sqrt() * beta / (1 - ab)
+            xtc = (1 - abp) * alpha.sqrt() / (1 - ab)
+            var = (beta * (1 - abp) / (1 - ab)).clamp(min=1e-20)
+            sd = (0.5 * var.log()).exp() * live
+            coef = torch.stack([k0, k1, x0c, xtc, sd, torch.zeros_like(ab), torch.zeros_like(ab),
+                                torch.zeros_like(ab)], dim=-1)
+            return coef.contiguous(), _M_DT_DDPM
+        if mode == "ddim":
+            var = (1 - abp) / (1 - ab) * (1 - ab / abp)
+            std = eta * torch.sqrt(var)
+            coef = torch.stack([k0, k1, ab.sqrt(), (1 - ab).sqrt(), (1 - abp - std**2).sqrt(), abp.sqrt(),
+                                std * live, torch.zeros_like(ab)], dim=-1)
+            return coef.contiguous(), (_M_DT_DDIM_NOISE if eta > 0 else _M_DT_DDIM)
+        raise ValueError(f"invalid mode {mode}")
+
+    @torch.inference_mode()
+    def p_step(self, x_t, steps, rng=None, mode: Literal["ddpm", "ddim"] = "ddim", eta: float = 0.0):
+        self._objective_id()
+        coef, mode_id = self._coefficients(steps, mode, eta)
+        prediction = self.model(x_t, steps.to(x_t.device))
+        # draw order as the reference: DDPM always draws; DDIM only when eta > 0 (:160,:174)
+        noise = self.randn_like(x_t, rng=rng) if mode_id != _M_DT_DDIM else None
+        return self._posterior(x_t, prediction, noise, coef.to(x_t.device), mode_id)
+
+    @torch.inference_mode()
+    def sample(self, batch_size: int, num_steps: int, progress: bool = True, rng=None,
+               return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm"):
+        """t = num_steps-1 ... 0 without respacing (discrete_time.py:182-201)."""
+        dev = self.device
+        self._objective_id()
+        x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=dev)
+        if return_all:
+            out = [x]
+        order = torch.arange(num_steps - 1, -1, -1)
+        coef, mode_id = self._coefficients(order, mode, 0.0)
+        coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
+        cond = order[:, None].expand(num_steps, batch_size).contiguous().to(dev)
+        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+            prediction = self.model(x, cond[i])
+            noise = self.randn_like(x, rng=rng) if mode_id != _M_DT_DDIM else None
+            x = self._posterior(x, prediction, noise, coef[i], mode_id)
+            if return_all:
+                out.append(x)
+        return torch.stack(out) if return_all else x

@@ -1,0 +1,269 @@
+"""Efficient U-Net denoiser whose forward pass is the HIP engine.
+
+Drop-in for the reference class (/root/reference/models/efficient_unet.py:188-295): same
+constructor arguments, same attributes (``resolution``, ``in_channels``, ``out_channels``,
+``coords``), same 268-key state dict, same ``forward(images (B,C,H,W), timesteps (B,))``.
+
+Structure here is deliberately NOT the reference's module zoo: parameters are registered from the
+flat table in ``spec.py`` on anonymous containers (so ``state_dict()`` / ``load_state_dict`` /
+``.to()`` keep working), and ``forward`` is one call into ``libr2dm_hip.so``
+(``r2dm_unet_forward``) which enqueues every kernel of the pass on the current stream.  The
+engine keeps its own packed copy of the weights (the "blob"); it is rebuilt lazily whenever the
+parameters may have changed (load_state_dict, .to(), in-place edits are NOT tracked -- call
+``invalidate()`` after editing parameters by hand).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .spec import Entry, UNetGeometry, unet_entries
+
+_FIR_DOWN = (0.125, 0.375, 0.375, 0.125)
+_FIR_UP = (0.25, 0.75, 0.75, 0.25)
+
+
+def _default_init(e: Entry, g: UNetGeometry) -> torch.Tensor:
+    """Same distributions as a freshly constructed reference network (PyTorch defaults +
+    zero_out, /root/reference/models/ops.py:9-11)."""
+    from .synthetic import fourier_tables
+
+    H, W = g.resolution
+    r = e.role
+    if r in ("conv_w", "linear_w"):
+        fan_in = int(torch.tensor(e.shape[1:]).prod())
+        bound = 1.0 / math.sqrt(fan_in)
+        return torch.empty(e.shape).uniform_(-bound, bound)
+    if r == "bias":
+        return torch.empty(e.shape).uniform_(-0.05, 0.05)
+    if r in ("conv_w_zero", "linear_w_zero", "bias_zero", "gn_b", "fourier_phase"):
+        return torch.zeros(e.shape)
+    if r == "gn_w":
+        return torch.ones(e.shape)
+    if r == "inv_sqrt2":
+        return torch.tensor(1 / math.sqrt(2)).float()
+    if r == "fir_down":
+        return torch.tensor(_FIR_DOWN)
+    if r == "fir_up":
+        return torch.tensor(_FIR_UP)
+    if r == "coords":
+        # models/encoding.py:80-89
+        phi = (0.5 - torch.arange(H) / H) * torch.pi
+        theta = (1 - torch.arange(W) / W) * 2 * torch.pi - torch.pi
+        phi, theta = torch.meshgrid([phi, theta], indexing="ij")
+        return torch.stack([phi, theta])[None]
+    if r == "fourier_freqs":
+        return fourier_tables(H, W)[0]
+    raise KeyError(r)
+
+
+class _Engine:
+    """Owns one r2dm_handle plus the torch tensors (blob, workspace) it points into."""
+
+    def __init__(self, g: UNetGeometry, max_batch: int):
+        L = _lib.lib()
+        cfg = _lib.Config(
+            in_channels=g.in_channels, out_channels=g.out_channels, height=g.resolution[0], width=g.resolution[1],
+            base_channels=g.base_channels, temb_channels=g.temb_channels,
+            channel_multiplier=(ctypes.c_int32 * 4)(*g.channel_multiplier),
+            num_residual_blocks=(ctypes.c_int32 * 4)(*g.num_residual_blocks),
+            gn_num_groups=g.gn_num_groups, gn_eps=g.gn_eps, attn_num_heads=g.attn_num_heads,
+            coord_channels=g.coord_channels, max_batch=max_batch)
+        h = ctypes.c_void_p()
+        _lib.check(L.r2dm_create(ctypes.byref(h), ctypes.byref(cfg)))
+        self.h = h
+        self.max_batch = max_batch
+        self.out_channels = g.out_channels
+        self.blob: Optional[torch.Tensor] = None
+        self.workspace: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().r2dm_destroy(self.h)
+        except Exception:
+            pass
+
+    # -- weights -----------------------------------------------------------------------------
+    def slots(self):
+        L = _lib.lib()
+        info = _lib.TensorInfo()
+        for i in range(L.r2dm_num_tensors(self.h)):
+            _lib.check(L.r2dm_tensor_at(self.h, i, ctypes.byref(info)))
+            yield i, info.key.decode(), int(info.numel)
+
+    def blob_bytes(self) -> int:
+        return int(_lib.lib().r2dm_blob_bytes(self.h))
+
+    def bind(self, blob: torch.Tensor):
+        _lib.require_gpu(blob, "weight blob")
+        assert blob.dtype == torch.uint8 and blob.is_contiguous()
+        _lib.check(_lib.lib().r2dm_bind_blob(self.h, blob.data_ptr(), blob.numel()))
+        self.blob = blob
+
+    def load(self, tensors: Dict[str, torch.Tensor], device: torch.device):
+        """Pack `tensors` (U-Net state-dict keys + the two '__' constants) into a fresh blob."""
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            self.bind(torch.zeros(self.blob_bytes(), dtype=torch.uint8, device=device))
+            st = _lib.stream_ptr(device)
+            keep = []
+            for i, key, numel in self.slots():
+                if key not in tensors:
+                    raise _lib.R2DMError(f"missing tensor {key!r} for the HIP engine")
+                t = _lib.f32c(tensors[key]).to(device)
+                keep.append(t)
+                _lib.check(L.r2dm_load_tensor(self.h, i, t.data_ptr(), t.numel(), st))
+            torch.cuda.current_stream(device).synchronize()  # sources may be freed after this
+
+    # -- forward -----------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        L = _lib.lib()
+        B = x.shape[0]
+        dev = x.device
+        need = int(L.r2dm_workspace_bytes(self.h, B))
+        if self.workspace is None or self.workspace.numel() < need or self.workspace.device != dev:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, self.out_channels, *x.shape[2:], device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.r2dm_unet_forward(self.h, x.data_ptr(), cond.data_ptr(), out.data_ptr(), B,
+                                           self.workspace.data_ptr(), self.workspace.numel(), _lib.stream_ptr(dev)))
+        return out
+
+
+class EfficientUNet(nn.Module):
+    def __init__(
+        self,
+        in_channels: int,
+        resolution,
+        out_channels: Optional[int] = None,
+        base_channels: int = 128,
+        temb_channels: Optional[int] = None,
+        channel_multiplier=(1, 2, 4, 8),
+        num_residual_blocks=(3, 3, 3, 3),
+        gn_num_groups: int = 32 // 4,
+        gn_eps: float = 1e-6,
+        attn_num_heads: int = 8,
+        coords_encoding: Optional[str] = "spherical_harmonics",
+        ring: bool = True,
+        max_batch: int = 8,
+    ):
+        super().__init__()
+        if not ring:
+            raise NotImplementedError("ring=False: the LiDAR models are always built with ring=True "
+                                      "(/root/reference/utils/inference.py:50)")
+        self.geometry = UNetGeometry.make(
+            in_channels=in_channels, resolution=resolution, out_channels=out_channels, base_channels=base_channels,
+            temb_channels=temb_channels, channel_multiplier=channel_multiplier,
+            num_residual_blocks=num_residual_blocks, gn_num_groups=gn_num_groups, gn_eps=gn_eps,
+            attn_num_heads=attn_num_heads, coords_encoding=coords_encoding)
+        self.geometry.coord_channels  # raises for encodings outside the built scope
+        self.resolution = self.geometry.resolution
+        self.in_channels = in_channels
+        self.out_channels = self.geometry.out_channels
+        self.max_batch = max_batch
+        for e in unet_entries(self.geometry):
+            self._register(e, _default_init(e, self.geometry))
+        self._engine: Optional[_Engine] = None
+        self._packed_for = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+
+    # -- generic parameter tree ----------------------------------------------------------------
+    def _register(self, e: Entry, value: torch.Tensor):
+        mod: nn.Module = self
+        *path, leaf = e.key.split(".")
+        for name in path:
+            if not hasattr(mod, name):
+                mod.add_module(name, nn.Module())
+            mod = getattr(mod, name)
+        if e.kind == "param":
+            mod.register_parameter(leaf, nn.Parameter(value.float()))
+        else:
+            mod.register_buffer(leaf, value.float())
+
+    def invalidate(self):
+        """Forget the packed weights; they are rebuilt on the next forward."""
+        self._packed_for = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
+
+    # -- constants the engine wants precomputed -------------------------------------------------
+    @torch.no_grad()
+    def _constants(self, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        g = self.geometry
+        out = {}
+        if g.coords_encoding == "fourier_features":
+            # models/encoding.py:141-146, evaluated once: coords are constant across steps and batch
+            z = torch.nn.functional.conv2d(sd["coords"].float(), sd["coords_encoding.freqs"].float(),
+                                           sd["coords_encoding.phase"].float())
+            out["__cenc"] = torch.cat([z.sin(), z.cos()], dim=1)[0]
+        half = g.base_channels // 2
+        # models/ops.py:22-23 (host float32, exactly the reference expression)
+        hcoef = -math.log(10_000) / (half - 1)
+        out["__sin_freqs"] = torch.exp(hcoef * torch.arange(half)).to(sd["coords"].device)
+        return out
+
+    def _check_fixed_buffers(self, sd: Dict[str, torch.Tensor]):
+        for k, v in sd.items():
+            want = _FIR_DOWN if k.endswith("downsample.1.kernel") else _FIR_UP if k.endswith("upsample.0.kernel") else None
+            if want is not None and not torch.allclose(v.detach().float().cpu(), torch.tensor(want)):
+                raise _lib.R2DMError(f"{k}={v.tolist()}: the HIP resamplers implement the fixed [1,3,3,1] window only")
+
+    def _ensure_packed(self, device: torch.device):
+        key = (device.type, device.index)
+        if self._engine is not None and self._packed_for == key:
+            return
+        if self._engine is None:
+            self._engine = _Engine(self.geometry, self.max_batch)
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        self._check_fixed_buffers(sd)
+        sd.update(self._constants(sd))
+        self._engine.load(sd, device)
+        self._packed_for = key
+
+    # -- weight sharing across GPUs (one RCCL broadcast instead of N loads) ----------------------
+    def packed_weights(self, device=None) -> torch.Tensor:
+        """The engine's packed weight blob (uint8 tensor on the GPU), building it if necessary."""
+        device = torch.device(device) if device is not None else self.coords.device
+        if device.type != "cuda":
+            raise _lib.R2DMError(f"packed weights live on the GPU; got device {device}")
+        self._ensure_packed(device)
+        return self._engine.blob
+
+    def adopt_packed_weights(self, blob: torch.Tensor):
+        """Bind a blob produced by ``packed_weights()`` of an identically configured model
+        (e.g. received through ``torch.distributed.broadcast``) without loading a state dict."""
+        if self._engine is None:
+            self._engine = _Engine(self.geometry, self.max_batch)
+        if blob.numel() != self._engine.blob_bytes():
+            raise _lib.R2DMError(f"blob has {blob.numel()} bytes, engine expects {self._engine.blob_bytes()}")
+        self._engine.bind(blob)
+        self._packed_for = (blob.device.type, blob.device.index)
+
+    def packed_weight_bytes(self) -> int:
+        if self._engine is None:
+            self._engine = _Engine(self.geometry, self.max_batch)
+        return self._engine.blob_bytes()
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def forward(self, images: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        _lib.require_gpu(images, "images")
+        if images.dim() != 4 or images.shape[1] != self.in_channels or tuple(images.shape[2:]) != self.resolution:
+            raise ValueError(f"expected (B,{self.in_channels},{self.resolution[0]},{self.resolution[1]}), "
+                             f"got {tuple(images.shape)}")
+        x = _lib.f32c(images)
+        B = x.shape[0]
+        if timesteps.dim() == 0:  # efficient_unet.py:273-274
+            timesteps = timesteps[None].repeat_interleave(B, dim=0)
+        cond = _lib.f32c(timesteps.to(x.device))  # efficient_unet.py:275 `timesteps.to(h)`
+        if cond.shape != (B,):
+            raise ValueError(f"timesteps must have shape ({B},), got {tuple(timesteps.shape)}")
+        self._ensure_packed(x.device)
+        return self._engine.forward(x, cond)

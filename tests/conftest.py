@@ -1,0 +1,57 @@
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore", category=UserWarning)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN_RES = (16, 128)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+
+    return get
+
+
+_CKPT = {}
+
+
+def synthetic_ckpt(**kw):
+    """Cached synthetic checkpoints (regenerated deterministically, never stored)."""
+    from r2dm_amd import synthetic
+
+    key = tuple(sorted(kw.items()))
+    if key not in _CKPT:
+        _CKPT[key] = synthetic.synthetic_checkpoint(seed=0, **kw)
+    return _CKPT[key]
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
+
+
+def max_abs(a, b):
+    return (a.double() - b.double()).abs().max().item()

@@ -1,0 +1,130 @@
+"""The oracle (oracle/r2dm_oracle.py) against the golden vectors captured from the real reference
+(tests/golden/make_golden.py).  CPU only.  Tolerances: the oracle restates the same float32 torch
+ops, so most checks are exact or at the 1e-6 level (different but equivalent op grouping)."""
+import math
+
+import pytest
+import torch
+
+from conftest import GOLDEN_RES, max_abs, synthetic_ckpt
+from oracle import r2dm_oracle as O
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return O.strip_prefix(synthetic_ckpt(resolution=GOLDEN_RES)["ema_weights"])
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return O.UNetConfig(resolution=GOLDEN_RES)
+
+
+def test_ops_conv_and_resample(golden, sd):
+    g = golden("ops")
+    p = "d_block1.residual_blocks.1."
+    assert max_abs(O.conv_ring(g["conv3_x"], sd[p + "conv1.weight"], sd[p + "conv1.bias"]), g["conv3_y"]) == 0
+    q = "u_block3.residual_blocks.0."
+    assert max_abs(O.conv_ring(g["conv1_x"], sd[q + "skip.weight"], sd[q + "skip.bias"]), g["conv1_y"]) == 0
+    assert max_abs(O.fir_down2(g["down_x"]), g["down_y"]) < 1e-6
+    assert max_abs(O.fir_up2(g["up_x"]), g["up_y"]) < 1e-6
+
+
+def test_ops_norm_embed(golden, sd, cfg):
+    g = golden("ops")
+    p = "d_block1.residual_blocks.1."
+    y = O.group_norm(g["gn_x"], 8, 1e-6, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    assert max_abs(y, g["gn_y"]) < 5e-6
+    ss = torch.nn.functional.linear(O.silu(g["temb"]), sd[p + "norm2.proj.1.weight"], sd[p + "norm2.proj.1.bias"])
+    sc, sh = ss[:, :, None, None].chunk(2, dim=1)
+    y = O.group_norm(g["adagn_x"], 8, 1e-6, None, None) * (1 + sc) + sh
+    assert max_abs(y, g["adagn_y"]) < 5e-6
+    assert max_abs(O.sinusoidal_embedding(g["sin_t"], 64), g["sin_y"]) == 0
+    assert max_abs(O.time_embedding(sd, cfg, g["sin_t"]), g["temb_y"]) < 1e-6
+    f = O.fourier_features(sd["coords"], sd["coords_encoding.freqs"], sd["coords_encoding.phase"])
+    assert max_abs(f, g["fourier_y"]) == 0
+    fr, ph = O.fourier_tables(*GOLDEN_RES)
+    assert torch.equal(fr, sd["coords_encoding.freqs"]) and torch.equal(ph, sd["coords_encoding.phase"])
+
+
+def test_ops_blocks(golden, sd, cfg):
+    g = golden("ops")
+    t = g["temb"]
+    assert max_abs(O.residual_block(sd, "d_block1.residual_blocks.1.", cfg, g["res_plain_x"], t), g["res_plain_y"]) < 1e-5
+    assert max_abs(O.residual_block(sd, "u_block3.residual_blocks.0.", cfg, g["res_skip_x"], t), g["res_skip_y"]) < 1e-5
+    assert max_abs(O.self_attention_block(sd, "d_block4.self_attn_block.", cfg, g["attn_x"]), g["attn_y"]) < 1e-5
+    assert max_abs(O.self_attention_block(sd, "u_block4.self_attn_block.", cfg, g["attn_u_x"]), g["attn_u_y"]) < 1e-5
+    assert max_abs(O.block(sd, "d_block2.", cfg, 3, g["blk_down_x"], t), g["blk_down_y"]) < 2e-5
+    assert max_abs(O.block(sd, "u_block3.", cfg, 3, g["blk_up_x"], t), g["blk_up_y"]) < 2e-5
+
+
+def test_unet_forward(golden, sd, cfg):
+    g = golden("unet")
+    for i, c in enumerate(g["conds"].tolist()):
+        y = O.unet_forward(sd, cfg, g["x"], torch.full((2,), c))
+        assert max_abs(y, g["y"][i]) < 2e-5, c
+    assert max_abs(O.unet_forward(sd, cfg, g["x"], g["cond_mixed"]), g["y_mixed"]) < 2e-5
+    assert g["y"].abs().max() > 0.1  # non-vacuous: the synthetic network is not the zero function
+
+
+def test_schedule(golden):
+    g = golden("schedule")
+    for S in (8, 32, 256):
+        t = torch.linspace(1.0, 0.0, S + 1)
+        lam = O.log_snr_cosine(t)
+        a, s = O.alpha_sigma(lam)
+        assert torch.equal(lam, g[f"lam{S}"]) and torch.equal(a, g[f"alpha{S}"]) and torch.equal(s, g[f"sigma{S}"])
+        assert torch.equal(-torch.special.expm1(lam[:-1] - lam[1:]), g[f"c{S}"])
+    assert abs(g["lam256"][0].item() + 15) < 1e-4 and abs(g["lam256"][-1].item() - 15) < 1e-4
+
+
+@pytest.mark.parametrize("obj", ["eps", "v", "x_0"])
+def test_p_step(golden, cfg, obj):
+    g = golden("p_step")
+    sd = O.strip_prefix(synthetic_ckpt(resolution=GOLDEN_RES, prediction_type=obj)["ema_weights"])
+    net = lambda x, c: O.unet_forward(sd, cfg, x, c)
+    for mode, eta in (("ddpm", 0.0), ("ddim", 0.0), ("ddim", 0.5)):
+        for (t, s) in ((1.0, 0.875), (0.5, 0.375), (0.125, 0.0)):
+            y = O.p_step_continuous(net, g["x_t"], torch.full((2,), t), torch.full((2,), s), g["z"], mode, eta, obj)
+            assert max_abs(y, g[f"{obj}_{mode}_{eta}_{t}_{s}"]) < 1e-4, (mode, eta, t, s)
+
+
+@pytest.mark.parametrize("mode", ["ddpm", "ddim"])
+def test_sample_noise_tape(golden, sd, cfg, mode):
+    g = golden(f"sample_{mode}")
+    net = lambda x, c: O.unet_forward(sd, cfg, x, c)
+    out = O.sample_continuous(net, (2, 2, *GOLDEN_RES), 8, noises=list(g["noise"]), return_all=True, mode=mode)
+    assert out.shape == g["out"].shape
+    assert max_abs(out, g["out"]) < 2e-4
+
+
+def test_sample_seeded(golden, sd, cfg):
+    g = golden("sample_seeded")
+    net = lambda x, c: O.unet_forward(sd, cfg, x, c)
+    rng = [torch.Generator("cpu").manual_seed(int(s)) for s in g["seeds"]]
+    out = O.sample_continuous(net, (2, 2, *GOLDEN_RES), 4, rng=rng)
+    assert max_abs(out, g["out"]) < 2e-4
+
+
+def test_discrete(golden, cfg):
+    g = golden("discrete")
+    ck = synthetic_ckpt(resolution=GOLDEN_RES, timestep_type="discrete", num_training_steps=1000, noise_schedule="linear")
+    sd = O.strip_prefix(ck["ema_weights"])
+    tabs = O.discrete_tables(1000, "linear")
+    assert torch.equal(tabs[0], g["beta"][:, 0, 0, 0]) and torch.equal(tabs[1], g["alpha_bar"][:, 0, 0, 0])
+    net = lambda x, c: O.unet_forward(sd, cfg, x, c)
+    for mode in ("ddpm", "ddim"):
+        for st in (999, 500, 0):
+            y = O.p_step_discrete(net, tabs, g["x_t"], torch.full((2,), st).long(), g["z"], mode)
+            assert max_abs(y, g[f"{mode}_{st}"]) < 1e-4, (mode, st)
+    x = g["sample_noise"][0]
+    for i, t in enumerate(reversed(range(16))):
+        x = O.p_step_discrete(net, tabs, x, torch.full((2,), t).long(), g["sample_noise"][i + 1], "ddpm")
+        assert max_abs(x, g["sample_out"][i + 1]) < 3e-4, t
+
+
+def test_lidar(golden):
+    g = golden("lidar")
+    y = O.lidar_postprocess(g["x"], g["ray_angles"])
+    assert max_abs(y, g["y"]) < 1e-4
+    assert torch.allclose(O.hdl64e_ray_angles(*GOLDEN_RES), g["ray_angles"], atol=1e-7)

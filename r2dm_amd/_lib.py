@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libr2dm_hip.so")
+LIB_PATH = os.environ.get("R2DM_HIP_LIB", os.path.join(_HERE, "libr2dm_hip.so"))
 
 
 class R2DMError(RuntimeError):

@@ -28,7 +28,11 @@ struct Src {
 __device__ __forceinline__ float silu_f(float v) {
     // x * sigmoid(x) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each).  Absolute error
     // <= ~2e-7*|v|, i.e. fp32-roundoff class like the convolution it feeds (parity budget ~1e-6).
+#ifdef R2DM_ACCURATE_SILU
+    return v / (1.0f + expf(-v));
+#else
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+#endif
 }
 
 // XCD-aware bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): logical ids that

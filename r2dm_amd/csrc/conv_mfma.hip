@@ -11,13 +11,16 @@
 // GEMM view: M = Cout, N = pixels, K = Cin*taps.  One MFMA v_mfma_f32_32x32x2_f32 multiplies a
 // 32(co) x 2(k) weight fragment with a 2(k) x 32(px) activation fragment; k-pairs are two adjacent
 // input channels at one tap.  fp32-in/fp32-accumulate MFMA is bit-equivalent to an fmaf chain, so
-// the 1e-4 sampling-parity budget is untouched while the VALU stays free for the fused prologue.
+// the sampling-parity budget is untouched while the VALU stays free for the fused prologue.
 //
 // Block = 256 threads = 4 waves, tile = CO_T output channels x (TH x TW) pixels, K walked in chunks
-// of CK input channels.  Per chunk the (TH+2)x(TW+2) halo tile of each channel (wrap in W, zero in H,
-// prologue applied once) and the chunk's packed weights are staged into LDS; the next chunk's global
-// loads are issued before the MFMA loop of the current one and written to the other LDS buffer after
-// it (one barrier per chunk).
+// of CK input channels through a double-buffered LDS stage (one barrier per chunk):
+//   * activations: (TH+2)x(TW+2) halo tile per channel (wrap in W, zero in H), global -> registers
+//     (issued before the chunk's MFMAs) -> prologue -> LDS (after them);
+//   * weights: the chunk's packed [CK][taps][CO_T] slab is contiguous in HBM: 16-byte loads -> registers
+//     -> ds_write_b128, same timing as the activations;
+// Accuracy: with ACC2 the accumulators are flushed into a second register set every 64 input
+// channels (576 products), so roundoff grows with sqrt(576) not sqrt(K) (K up to 4608).
 #include "common.h"
 
 namespace r2dm {
@@ -31,22 +34,28 @@ struct ConvCfg {
     static constexpr int NX = CK * XPLANE;
     static constexpr int NX_PAD = (NX + 3) & ~3;
     static constexpr int NW = CK * TAPS * CO_T;
+    static constexpr int NW4 = NW / 4;
+    static constexpr int NWT = (NW4 + 255) / 256;
     static constexpr int BUF = NX_PAD + NW;
     static constexpr int NXT = (NX + 255) / 256;
-    static constexpr int NWT = (NW / 4 + 255) / 256;
     static constexpr int MR = CO_T / WCO / 32;
     static constexpr int SEGW = TW / 32;
     static constexpr int NSEG = TH * SEGW;
     static constexpr int NR = NSEG / WPX;
+    static constexpr int NSTEP = (CK / 2) * TAPS;
+    static constexpr int FLUSH = 64 / CK;  // chunks per accumulator flush (ACC2)
     static_assert(WCO * WPX == 4, "4 waves per block");
-    static_assert(MR >= 1 && NR >= 1 && CK % 2 == 0 && NW % 4 == 0, "tile shape");
-    static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
+    static_assert(MR >= 1 && NR >= 1 && CK % 2 == 0 && NW % 4 == 0 && 64 % CK == 0, "tile shape");
+    static constexpr size_t lds_bytes(int cin, bool pro) {
+        return (2 * (size_t)BUF + (pro ? 2 * (size_t)((cin + 1) & ~1) : 0)) * sizeof(float);
+    }
 };
 
-template <int TAPS, int CO_T, int TH, int TW, int WCO, int WPX, int CK, int PRO>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
+template <int TAPS, int CO_T, int TH, int TW, int WCO, int WPX, int CK, int PRO, bool ACC2, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p) {
     using C = ConvCfg<TAPS, CO_T, TH, TW, WCO, WPX, CK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* affs = reinterpret_cast<float2*>(smem + 2 * C::BUF);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int wave_co = wave % WCO, wave_px = wave / WCO;
 
     const int H = p.H, W = p.W;
-    const long HW = (long)H * W;
+    const int HW = H * W;
     const int nTw = (W + TW - 1) / TW, nTh = (H + TH - 1) / TH;
     const int nCoT = (p.Cout + CO_T - 1) / CO_T;
     int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int b = L / nTh;
 
     // ---- per-thread staging map: element e = tid + i*256 of the [CK][XR][XS] halo tile ----
-    int pk[C::NXT];  // bit31: row outside the image; bits 24..30: channel within chunk; low: y*W+x
+    int pk[C::NXT];  // sign: outside the image / past the tile; bits 24..28: channel in chunk; low 24: y*W+x
 #pragma unroll
     for (int i = 0; i < C::NXT; ++i) {
         const int e = tid + i * 256;
@@ -80,49 +89,67 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         pk[i] = ok ? ((cl << 24) | (gr * W + gc)) : (int)0x80000000;
     }
 
+    if (PRO != PRO_NONE) {  // folded GroupNorm affine of this sample, all input channels
+        for (int c = tid; c < p.Cin; c += 256) affs[c] = p.aff[(size_t)b * p.Cin + c];
+    }
+
     const float* wsrc = p.w + (size_t)cot * p.CinPad * TAPS * CO_T;
+    const float* xb0 = p.x.p0 + b * p.x.bs0;
+    const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
+    const int c0 = p.x.c0;
     float xv[C::NXT];
-    float2 xa[C::NXT];
     f32x4 wv[C::NWT];
 
-    auto load_chunk = [&](int ci0) {
-#pragma unroll
-        for (int i = 0; i < C::NXT; ++i) {
-            const int ci = ci0 + ((pk[i] >> 24) & 0x7f);
-            const bool ok = pk[i] >= 0 && ci < p.Cin;
-            xv[i] = 0.f;
-            if (PRO != PRO_NONE) xa[i] = make_float2(0.f, 0.f);
-            if (ok) {
-                xv[i] = p.x.plane(b, ci, HW)[pk[i] & 0xffffff];
-                if (PRO != PRO_NONE) xa[i] = p.aff[(size_t)b * p.Cin + ci];
-            }
-        }
+    auto stage_load = [&](int ci0) {
+        // weights: the chunk's [CK][taps][CO_T] slab is contiguous: 16-byte loads, ds_write_b128 after the MFMAs.
+        // (LDS-DMA was tried: with it hipcc must drain vmcnt(0) before the first ds_read of the chunk because the
+        // DMA target and the fragment reads live in one LDS array, which serialises HBM latency with the MFMAs.)
         const f32x4* w4 = reinterpret_cast<const f32x4*>(wsrc + (size_t)ci0 * TAPS * CO_T);
 #pragma unroll
         for (int i = 0; i < C::NWT; ++i) {
             const int e = tid + i * 256;
-            if (e < C::NW / 4) wv[i] = w4[e];
+            if (C::NW4 % 256 == 0 || e < C::NW4) wv[i] = w4[e];
+        }
+        // activations: branch-free loads (invalid elements read a safe address and are zeroed at store)
+        if (ci0 + CK <= c0 || ci0 >= c0) {
+            const float* base = ci0 >= c0 ? xb1 + (long)(ci0 - c0) * HW : xb0 + (long)ci0 * HW;
+#pragma unroll
+            for (int i = 0; i < C::NXT; ++i) {
+                const int cl = (pk[i] >> 24) & 0x1f;
+                const bool ok = pk[i] >= 0 && ci0 + cl < p.Cin;
+                const int off = cl * HW + (pk[i] & 0xffffff);
+                xv[i] = base[ok ? off : 0];
+            }
+        } else {  // the chunk straddles the concat seam (only in_conv: 2 image + coordinate channels)
+#pragma unroll
+            for (int i = 0; i < C::NXT; ++i) {
+                const int ci = ci0 + ((pk[i] >> 24) & 0x1f);
+                const bool ok = pk[i] >= 0 && ci < p.Cin;
+                const float* pl = ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW;
+                xv[i] = ok ? pl[pk[i] & 0xffffff] : 0.f;
+            }
         }
     };
-    auto store_chunk = [&](float* buf, int ci0) {
+    auto stage_store = [&](float* buf, int ci0) {
 #pragma unroll
         for (int i = 0; i < C::NXT; ++i) {
             const int e = tid + i * 256;
+            const int ci = ci0 + ((pk[i] >> 24) & 0x1f);
+            const bool ok = pk[i] >= 0 && ci < p.Cin;
             float v = xv[i];
             if (PRO != PRO_NONE) {
-                const int ci = ci0 + ((pk[i] >> 24) & 0x7f);
-                const bool ok = pk[i] >= 0 && ci < p.Cin;
-                v = v * xa[i].x + xa[i].y;
+                const float2 ad = affs[ok ? ci : 0];
+                v = v * ad.x + ad.y;
                 if (PRO == PRO_AFFINE_SILU) v = silu_f(v);
-                v = ok ? v : 0.f;  // zero padding applies to the *activated* tensor
             }
-            if (e < C::NX) buf[e] = v;
+            v = ok ? v : 0.f;  // zero padding applies to the *activated* tensor
+            if (C::NX % 256 == 0 || e < C::NX) buf[e] = v;
         }
         f32x4* w4 = reinterpret_cast<f32x4*>(buf + C::NX_PAD);
 #pragma unroll
         for (int i = 0; i < C::NWT; ++i) {
             const int e = tid + i * 256;
-            if (e < C::NW / 4) w4[e] = wv[i];
+            if (C::NW4 % 256 == 0 || e < C::NW4) w4[e] = wv[i];
         }
     };
 
@@ -136,63 +163,99 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int woff = C::NX_PAD + hi * TAPS * CO_T + wave_co * (CO_T / WCO) + l31;
 
     f32x16 acc[C::MR][C::NR];
+    f32x16 acc2[ACC2 ? C::MR : 1][ACC2 ? C::NR : 1];
 #pragma unroll
     for (int m = 0; m < C::MR; ++m)
 #pragma unroll
         for (int n = 0; n < C::NR; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[m][n][r] = 0.f;
+                if (ACC2) acc2[m][n][r] = 0.f;
+            }
 
     const int nchunks = p.CinPad / CK;
-    load_chunk(0);
-    store_chunk(smem, 0);
+    stage_load(0);
+    if (PRO != PRO_NONE) __syncthreads();  // affs visible
+    stage_store(smem, 0);
     __syncthreads();
 
     for (int k = 0; k < nchunks; ++k) {
         const float* buf = smem + (k & 1) * C::BUF;
+        float* nbuf = smem + ((k + 1) & 1) * C::BUF;
         const bool more = k + 1 < nchunks;
-        if (more) load_chunk((k + 1) * CK);
+        if (more) stage_load((k + 1) * CK);
+
+        float fa[2][C::MR], fb[2][C::NR];
+        auto frag = [&](int s, float* a, float* bb) {
+            const int cp = s / TAPS, t = s % TAPS;
+            const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
 #pragma unroll
-        for (int cp = 0; cp < CK / 2; ++cp) {
+            for (int m = 0; m < C::MR; ++m) a[m] = buf[woff + (cp * 2 * TAPS + t) * CO_T + m * 32];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
-                float a[C::MR], bb[C::NR];
+            for (int n = 0; n < C::NR; ++n) bb[n] = buf[xoff[n] + cp * 2 * C::XPLANE + dy * C::XS + dx];
+        };
+        frag(0, fa[0], fb[0]);
 #pragma unroll
-                for (int m = 0; m < C::MR; ++m) a[m] = buf[woff + (cp * 2 * TAPS + t) * CO_T + m * 32];
+        for (int s = 0; s < C::NSTEP; ++s) {
+            if (s + 1 < C::NSTEP) frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
-                for (int n = 0; n < C::NR; ++n) bb[n] = buf[xoff[n] + cp * 2 * C::XPLANE + dy * C::XS + dx];
+            for (int m = 0; m < C::MR; ++m)
 #pragma unroll
-                for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-                    for (int n = 0; n < C::NR; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
-            }
+                for (int n = 0; n < C::NR; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][m], fb[s & 1][n], acc[m][n], 0, 0, 0);
         }
-        if (more) store_chunk(smem + ((k + 1) & 1) * C::BUF, (k + 1) * CK);
+        if (ACC2 && ((k + 1) % C::FLUSH == 0)) {
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                for (int n = 0; n < C::NR; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc2[m][n][r] += acc[m][n][r];
+                        acc[m][n][r] = 0.f;
+                    }
+        }
+        if (more) stage_store(nbuf, (k + 1) * CK);
         __syncthreads();
     }
 
     // ---- epilogue: bias, residual, scale; D layout col = lane&31 (pixel), row = (r&3)+8(r>>2)+4hi ----
+    // Addresses are (wave-uniform base: SGPR pair) + (per-lane 32-bit offset) so that the 16..64 stores of a lane
+    // share one offset VGPR.  All loads of a 32x32 tile (bias, residual) are issued before its first store: the
+    // output may alias the residual as far as the compiler knows, and load-after-store would otherwise serialise
+    // an L2 round trip per element.
     const float sc = p.scale ? *p.scale : 1.0f;
+    const int co_u = cot * CO_T + wave_co * (CO_T / WCO);  // wave-uniform first output channel
+    float* yu = p.y + b * p.y_bs + (long)co_u * HW;
+    const float* ru = p.res ? p.res + b * p.res_bs + (long)co_u * HW : nullptr;
+    const float* bu = p.bias + co_u;
 #pragma unroll
     for (int n = 0; n < C::NR; ++n) {
         const int s = wave_px * C::NR + n;
         const int gr = th * TH + s / C::SEGW;
         const int gc = tw * TW + (s % C::SEGW) * 32 + l31;
-        if (gr >= H || gc >= W) continue;
-        const long sp = (long)gr * W + gc;
+        const bool px_ok = gr < H && gc < W;
+        const int loff = (px_ok ? gr * W + gc : 0) + 4 * hi * HW;
 #pragma unroll
         for (int m = 0; m < C::MR; ++m) {
+            float bv[16], rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cot * CO_T + wave_co * (CO_T / WCO) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (co < p.Cout) {
-                    float v = acc[m][n][r] + p.bias[co];
-                    if (p.res) v = p.res[b * p.res_bs + co * HW + sp] + v;
-                    if (p.scale) v *= sc;
-                    p.y[b * p.y_bs + co * HW + sp] = v;
-                }
+                const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+                const bool ok = co_u + cu + 4 * hi < p.Cout;
+                bv[r] = (bu + cu)[ok ? 4 * hi : 0];
+                if (ru) rv[r] = (ru + (long)cu * HW)[ok ? loff : 0];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[m][n][r];
+                if (ACC2) v += acc2[m][n][r];
+                v += bv[r];
+                if (ru) v = rv[r] + v;
+                if (p.scale) v *= sc;
+                if (px_ok && co_u + cu + 4 * hi < p.Cout) (yu + (long)cu * HW)[loff] = v;
             }
         }
     }
@@ -223,7 +286,13 @@ hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int t
 }
 
 // ---- dispatch ----
-constexpr int kCK3 = 8, kCK1 = 16;
+// tile variants:            CO_T  waves(co x px)  CK   acc regs/lane   blocks/CU target
+//   3x3  "A128"             128   2 x 2           4    128             2
+//   3x3  "B64"               64   1 x 4           4    64              3      (Cin <= 128)
+//   3x3  "B64 deep"          64   1 x 4           8    64 + 64 (ACC2)  2      (Cin > 128: long prefetch distance)
+//   3x3  "D32" (out_conv)    32   1 x 4           8    32              3
+//   1x1                   32/64/128               16
+constexpr int kCK3_128 = 4, kCK3_64 = 4, kCK3_64_DEEP = 8, kCK3_32 = 8, kCK1 = 16;
 
 int conv_pick_co_tile(int Cout, int taps, long px_batch) {
     (void)taps;
@@ -236,33 +305,34 @@ int conv_pick_co_tile(int Cout, int taps, long px_batch) {
 }
 
 int conv_cin_pad(int Cin, int taps, int co_tile) {
-    const int ck = taps == 9 ? (co_tile == 128 ? 4 : kCK3) : kCK1;
+    const int ck = taps == 9 ? (co_tile == 128 ? kCK3_128 : co_tile == 64 ? kCK3_64_DEEP : kCK3_32) : kCK1;
     return (Cin + ck - 1) / ck * ck;
 }
 
-template <int TAPS, int CO_T, int TH, int TW, int WCO, int WPX, int CK, int PRO>
+template <int TAPS, int CO_T, int WCO, int WPX, int CK, int PRO, bool ACC2, int OCC>
 static hipError_t launch_variant(const ConvParams& p, hipStream_t s) {
-    using C = ConvCfg<TAPS, CO_T, TH, TW, WCO, WPX, CK>;
-    auto kern = conv_mfma_kernel<TAPS, CO_T, TH, TW, WCO, WPX, CK, PRO>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    using C = ConvCfg<TAPS, CO_T, 4, 64, WCO, WPX, CK>;
+    auto kern = conv_mfma_kernel<TAPS, CO_T, 4, 64, WCO, WPX, CK, PRO, ACC2, OCC>;
+    const size_t lds = C::lds_bytes(p.Cin, PRO != PRO_NONE);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_lds = lds;
     }
-    const int nTw = (p.W + TW - 1) / TW, nTh = (p.H + TH - 1) / TH, nCoT = (p.Cout + CO_T - 1) / CO_T;
+    const int nTw = (p.W + 63) / 64, nTh = (p.H + 3) / 4, nCoT = (p.Cout + CO_T - 1) / CO_T;
     const long nblk = (long)nCoT * nTw * nTh * p.B;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
-template <int TAPS, int CO_T, int WCO, int WPX, int CK>
+template <int TAPS, int CO_T, int WCO, int WPX, int CK, bool ACC2, int OCC>
 static hipError_t launch_pro(const ConvParams& p, hipStream_t s) {
     switch (p.prologue) {
-        case PRO_NONE: return launch_variant<TAPS, CO_T, 4, 64, WCO, WPX, CK, PRO_NONE>(p, s);
-        case PRO_AFFINE: return launch_variant<TAPS, CO_T, 4, 64, WCO, WPX, CK, PRO_AFFINE>(p, s);
-        case PRO_AFFINE_SILU: return launch_variant<TAPS, CO_T, 4, 64, WCO, WPX, CK, PRO_AFFINE_SILU>(p, s);
+        case PRO_NONE: return launch_variant<TAPS, CO_T, WCO, WPX, CK, PRO_NONE, ACC2, OCC>(p, s);
+        case PRO_AFFINE: return launch_variant<TAPS, CO_T, WCO, WPX, CK, PRO_AFFINE, ACC2, OCC>(p, s);
+        case PRO_AFFINE_SILU: return launch_variant<TAPS, CO_T, WCO, WPX, CK, PRO_AFFINE_SILU, ACC2, OCC>(p, s);
     }
     return hipErrorInvalidValue;
 }
@@ -270,14 +340,22 @@ static hipError_t launch_pro(const ConvParams& p, hipStream_t s) {
 hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.CinPad != conv_cin_pad(p.Cin, p.taps, p.co_tile)) return hipErrorInvalidValue;
+    if (p.H * (long)p.W >= (1 << 24)) return hipErrorInvalidValue;
     if (p.taps == 9) {
-        if (p.co_tile == 128) return launch_pro<9, 128, 2, 2, 4>(p, s);
-        if (p.co_tile == 64) return launch_pro<9, 64, 1, 4, kCK3>(p, s);
-        if (p.co_tile == 32) return launch_pro<9, 32, 1, 4, kCK3>(p, s);
+        if (p.co_tile == 128) return launch_pro<9, 128, 2, 2, kCK3_128, false, 2>(p, s);
+        if (p.co_tile == 64) {
+            // long reductions (K = 9*Cin > 1152) get the two-level accumulator
+#ifdef R2DM_ACC2_ALL
+            if (true) return launch_pro<9, 64, 1, 4, kCK3_64_DEEP, true, 2>(p, s);
+#endif
+            return p.Cin > 128 ? launch_pro<9, 64, 1, 4, kCK3_64_DEEP, true, 2>(p, s)
+                               : launch_pro<9, 64, 1, 4, kCK3_64, false, 3>(p, s);
+        }
+        if (p.co_tile == 32) return launch_pro<9, 32, 1, 4, kCK3_32, false, 3>(p, s);
     } else if (p.taps == 1) {
-        if (p.co_tile == 128) return launch_pro<1, 128, 2, 2, kCK1>(p, s);
-        if (p.co_tile == 64) return launch_pro<1, 64, 1, 4, kCK1>(p, s);
-        if (p.co_tile == 32) return launch_pro<1, 32, 1, 4, kCK1>(p, s);
+        if (p.co_tile == 128) return launch_pro<1, 128, 2, 2, kCK1, false, 2>(p, s);
+        if (p.co_tile == 64) return launch_pro<1, 64, 1, 4, kCK1, false, 3>(p, s);
+        if (p.co_tile == 32) return launch_pro<1, 32, 1, 4, kCK1, false, 3>(p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -10,10 +10,18 @@
 
 namespace r2dm {
 
-__device__ __forceinline__ float wave_sum_f(float v) {
+// These vectors condition EVERY AdaGN layer (a common-mode error here is seen 24 times), and the whole kernel
+// is a few hundred KFLOP: accumulate in fp64 and use the accurate transcendental paths, so that the embedding
+// and the projections are correctly rounded fp32 values of the reference expressions.
+__device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+__device__ __forceinline__ float silu_exact(float v) {
+    const double d = (double)v;
+    return (float)(d / (1.0 + exp(-d)));
 }
 
 // grid = B, block = 256.  One wave per output row, lanes stride the reduction dimension.
@@ -24,24 +32,24 @@ __global__ __launch_bounds__(256) void time_embedding_kernel(EmbedParams p) {
     const int b = blockIdx.x, half = p.base / 2;
     const float t = p.cond[b];
     for (int k = threadIdx.x; k < half; k += 256) {
-        const float arg = t * p.freqs[k];
-        emb[k] = sinf(arg);
-        emb[half + k] = cosf(arg);
+        const float arg = t * p.freqs[k];  // fp32 product, as the reference forms it (ops.py:24)
+        emb[k] = (float)sin((double)arg);
+        emb[half + k] = (float)cos((double)arg);
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int r = wave; r < p.T; r += 4) {
-        float acc = 0.f;
-        for (int k = lane; k < p.base; k += 64) acc += p.w1[(long)r * p.base + k] * emb[k];
-        acc = wave_sum_f(acc);
-        if (lane == 0) hid[r] = silu_f(acc + p.b1[r]);
+        double acc = 0.0;
+        for (int k = lane; k < p.base; k += 64) acc += (double)p.w1[(long)r * p.base + k] * (double)emb[k];
+        acc = wave_sum_d(acc);
+        if (lane == 0) hid[r] = silu_exact((float)(acc + (double)p.b1[r]));
     }
     __syncthreads();
     for (int r = wave; r < p.T; r += 4) {
-        float acc = 0.f;
-        for (int k = lane; k < p.T; k += 64) acc += p.w2[(long)r * p.T + k] * hid[k];
-        acc = wave_sum_f(acc);
-        if (lane == 0) p.act[(long)b * p.T + r] = silu_f(acc + p.b2[r]);
+        double acc = 0.0;
+        for (int k = lane; k < p.T; k += 64) acc += (double)p.w2[(long)r * p.T + k] * (double)hid[k];
+        acc = wave_sum_d(acc);
+        if (lane == 0) p.act[(long)b * p.T + r] = silu_exact((float)(acc + (double)p.b2[r]));
     }
 }
 
@@ -58,10 +66,10 @@ __global__ __launch_bounds__(256) void ada_proj_kernel(const float* __restrict__
     if (r >= rows) return;
     const float* wr = w + (long)r * T;
     for (int b = 0; b < B; ++b) {
-        float acc = 0.f;
-        for (int k = lane; k < T; k += 64) acc += wr[k] * act[(long)b * T + k];
-        acc = wave_sum_f(acc);
-        if (lane == 0) out[(long)b * rows + r] = acc + bias[r];
+        double acc = 0.0;
+        for (int k = lane; k < T; k += 64) acc += (double)wr[k] * (double)act[(long)b * T + k];
+        acc = wave_sum_d(acc);
+        if (lane == 0) out[(long)b * rows + r] = (float)(acc + (double)bias[r]);
     }
 }
 

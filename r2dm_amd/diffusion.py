@@ -238,27 +238,41 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         return self._log_snr_1d(steps)
 
     # -- host-side coefficient table -------------------------------------------------------
-    def _coefficients(self, step_t: torch.Tensor, step_s: torch.Tensor, mode: str, ddim_eta: float):
-        """Per-row scalars of continuous_time.py:203-229, float32 on the host.
-        Returns (cond (N,), coef (N,8), kernel mode)."""
-        step_t = step_t.detach().to("cpu", torch.float32)
-        step_s = step_s.detach().to("cpu", torch.float32)
-        lt, ls = self._log_snr_1d(step_t), self._log_snr_1d(step_s)
+    def _coefficient_row(self, t: torch.Tensor, s: torch.Tensor, mode: str, ddim_eta: float):
+        """Scalars of continuous_time.py:203-229 for ONE (t, s) pair, as 1-element float32 tensors."""
+        lt, ls = self._log_snr_1d(t), self._log_snr_1d(s)
         a_t, s_t = log_snr_to_alpha_sigma(lt)
         a_s, s_s = log_snr_to_alpha_sigma(ls)
         z = torch.zeros_like(lt)
         if mode == "ddpm":
             c = -expm1(lt - ls)
-            coef = torch.stack([a_t, s_t, a_s, s_s, c, s_s * c.sqrt(), z, z], dim=-1)
-            mode_id = _M_CT_DDPM
-        elif mode == "ddim":
+            return lt, torch.cat([a_t, s_t, a_s, s_s, c, s_s * c.sqrt(), z, z])
+        if mode == "ddim":
             c_1 = ddim_eta * s_s / s_t * (1 - a_t**2 / a_s**2).sqrt()
             c_2 = (1 - a_s**2 - c_1**2).sqrt()
-            coef = torch.stack([a_t, s_t, a_s, s_s, z, z, c_1, c_2], dim=-1)
-            mode_id = _M_CT_DDIM
-        else:
+            return lt, torch.cat([a_t, s_t, a_s, s_s, z, z, c_1, c_2])
+        raise ValueError(f"invalid mode {mode}")
+
+    def _coefficients(self, step_t: torch.Tensor, step_s: torch.Tensor, mode: str, ddim_eta: float):
+        """Per-row schedule scalars, float32 on the host.  Returns (cond (N,), coef (N,8), kernel mode).
+
+        Each row is evaluated on 1-element tensors: torch's CPU elementwise kernels round the last bit
+        differently in their SIMD body and in their scalar tail, and the reference evaluates the schedule on
+        (B,)-shaped tensors (continuous_time.py:203-206), i.e. on the scalar path for its CPU-runnable
+        batch sizes (BASELINE configs[0]: batch 1).  Row-wise evaluation reproduces those values bit for
+        bit and makes the table independent of the number of steps."""
+        step_t = step_t.detach().to("cpu", torch.float32).reshape(-1)
+        step_s = step_s.detach().to("cpu", torch.float32).reshape(-1)
+        if mode not in ("ddpm", "ddim"):
             raise ValueError(f"invalid mode {mode}")
-        return lt, coef.contiguous(), mode_id
+        memo, conds, rows = {}, [], []
+        for i in range(step_t.numel()):
+            key = (step_t[i].item(), step_s[i].item())
+            if key not in memo:
+                memo[key] = self._coefficient_row(step_t[i:i + 1], step_s[i:i + 1], mode, ddim_eta)
+            conds.append(memo[key][0])
+            rows.append(memo[key][1])
+        return torch.cat(conds), torch.stack(rows).contiguous(), (_M_CT_DDPM if mode == "ddpm" else _M_CT_DDIM)
 
     @torch.inference_mode()
     def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",

@@ -1,0 +1,75 @@
+"""Data-parallel sampling over independent seeds.
+
+The reference shards a DataLoader of *seeds* across ranks with Accelerate
+(/root/reference/sample_and_save.py:25-46) and every rank re-reads the checkpoint from disk.  Here:
+one process per GPU, contiguous seed shards, ONE RCCL broadcast of the packed weight blob over
+xGMI at start-up, and no collective inside the step loop (samples are independent).  Results are
+partition-invariant because every sample owns a generator seeded by its global seed
+(/root/reference/utils/inference.py:113-114, /root/reference/models/diffusion/base.py:81-85).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import torch
+
+
+def _dist():
+    import torch.distributed as td
+
+    return td if (td.is_available() and td.is_initialized()) else None
+
+
+def shard_seeds(seeds: Sequence[int], rank: int, world: int) -> List[int]:
+    """Contiguous split; the first (len % world) ranks get one extra seed (even_batches=False)."""
+    n = len(seeds)
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return list(seeds[lo: lo + base + (1 if rank < extra else 0)])
+
+
+def broadcast_tensor(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    td = _dist()
+    if td is not None and td.get_world_size() > 1:
+        td.broadcast(t, src=src)
+    return t
+
+
+def broadcast_packed_weights(model, device, src: int = 0) -> None:
+    """Rank `src` packs its weights into the engine blob; the blob is broadcast and adopted by all."""
+    td = _dist()
+    if td is None or td.get_world_size() == 1:
+        model.packed_weights(device)
+        return
+    if td.get_rank() == src:
+        blob = model.packed_weights(device)
+    else:
+        blob = torch.empty(model.packed_weight_bytes(), dtype=torch.uint8, device=device)
+    td.broadcast(blob, src=src)
+    if td.get_rank() != src:
+        model.adopt_packed_weights(blob)
+
+
+def sample_sharded(sample_fn: Callable[[List[int]], torch.Tensor], seeds: Sequence[int], gather: bool = True):
+    """Run ``sample_fn(my_seeds) -> (n_local, ...)`` on this rank's shard; optionally all-gather the
+    per-seed results (in global seed order) on every rank."""
+    td = _dist()
+    world = td.get_world_size() if td else 1
+    rank = td.get_rank() if td else 0
+    mine = shard_seeds(seeds, rank, world)
+    out = sample_fn(mine) if mine else None
+    if not gather or world == 1:
+        return out, mine
+    sizes = [len(shard_seeds(seeds, r, world)) for r in range(world)]
+    probe = out if out is not None else None
+    shape = [None]
+    td.broadcast_object_list(shape if rank else [tuple(probe.shape[1:])], src=0)
+    tail = shape[0] if rank else tuple(probe.shape[1:])
+    dev = out.device if out is not None else torch.device("cpu")
+    pad = max(sizes)
+    buf = torch.zeros(pad, *tail, device=dev, dtype=torch.float32)
+    if out is not None:
+        buf[: len(mine)] = out
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    td.all_gather(parts, buf)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)]), mine

@@ -200,14 +200,16 @@ class EfficientUNet(nn.Module):
         g = self.geometry
         out = {}
         if g.coords_encoding == "fourier_features":
-            # models/encoding.py:141-146, evaluated once: coords are constant across steps and batch
-            z = torch.nn.functional.conv2d(sd["coords"].float(), sd["coords_encoding.freqs"].float(),
-                                           sd["coords_encoding.phase"].float())
+            # models/encoding.py:141-146, evaluated once: coords are constant across steps and batch.
+            # Done on the HOST: arguments reach 2^9*pi and f*theta must be the exact float product before
+            # sin/cos; a GPU conv library (MIOpen) does not guarantee that and costs ~1e-5 on the U-Net output.
+            z = torch.nn.functional.conv2d(sd["coords"].float().cpu(), sd["coords_encoding.freqs"].float().cpu(),
+                                           sd["coords_encoding.phase"].float().cpu())
             out["__cenc"] = torch.cat([z.sin(), z.cos()], dim=1)[0]
         half = g.base_channels // 2
         # models/ops.py:22-23 (host float32, exactly the reference expression)
         hcoef = -math.log(10_000) / (half - 1)
-        out["__sin_freqs"] = torch.exp(hcoef * torch.arange(half)).to(sd["coords"].device)
+        out["__sin_freqs"] = torch.exp(hcoef * torch.arange(half))
         return out
 
     def _check_fixed_buffers(self, sd: Dict[str, torch.Tensor]):

@@ -1,0 +1,78 @@
+"""Test-side wrappers around the single-kernel C-ABI entry points of libr2dm_hip.so."""
+import torch
+
+from r2dm_amd import _lib
+
+
+def _st(t):
+    return _lib.stream_ptr(t.device)
+
+
+def conv2d_ring(x, w, b, aff=None, prologue=0, residual=None, scale=None):
+    L = _lib.lib()
+    B, cin, H, W = x.shape
+    cout, k = w.shape[0], w.shape[-1]
+    x, w, b = _lib.f32c(x), _lib.f32c(w), _lib.f32c(b)
+    packed = torch.empty(L.r2dm_conv_packed_elems(cout, cin, k, B, H, W), device=x.device)
+    y = torch.empty(B, cout, H, W, device=x.device)
+    sc = None if scale is None else torch.tensor([scale], device=x.device, dtype=torch.float32)
+    _lib.check(L.r2dm_conv2d_ring(x.data_ptr(), w.data_ptr(), b.data_ptr(), packed.data_ptr(), _lib.ptr(aff), prologue,
+                                  _lib.ptr(residual), _lib.ptr(sc), y.data_ptr(), B, cin, cout, H, W, k, _st(x)))
+    torch.cuda.synchronize()
+    return y
+
+
+def group_norm_affine(x, groups, eps, gamma=None, beta=None, ada=None):
+    L = _lib.lib()
+    B, C, H, W = x.shape
+    x = _lib.f32c(x)
+    scratch = torch.empty(L.r2dm_group_norm_scratch_bytes(B, groups), dtype=torch.uint8, device=x.device)
+    aff = torch.empty(B, C, 2, device=x.device)
+    stats = torch.empty(B, groups, 2, device=x.device)
+    _lib.check(L.r2dm_group_norm_affine(x.data_ptr(), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ada), scratch.data_ptr(),
+                                        aff.data_ptr(), stats.data_ptr(), B, C, H, W, groups, eps, _st(x)))
+    torch.cuda.synchronize()
+    return aff, stats
+
+
+def affine_act(x, aff, silu):
+    L = _lib.lib()
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    _lib.check(L.r2dm_affine_act(x.data_ptr(), aff.data_ptr(), y.data_ptr(), B, C, H * W, int(silu), _st(x)))
+    torch.cuda.synchronize()
+    return y
+
+
+def fir_down2(x):
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, H // 2, W // 2, device=x.device)
+    _lib.check(_lib.lib().r2dm_fir_down2(x.data_ptr(), y.data_ptr(), B, C, H, W, _st(x)))
+    torch.cuda.synchronize()
+    return y
+
+
+def fir_up2(x):
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, H * 2, W * 2, device=x.device)
+    _lib.check(_lib.lib().r2dm_fir_up2(x.data_ptr(), y.data_ptr(), B, C, H, W, _st(x)))
+    torch.cuda.synchronize()
+    return y
+
+
+def attention(qkv, heads):
+    B, C3, N = qkv.shape
+    C = C3 // 3
+    out = torch.empty(B, C, N, device=qkv.device)
+    _lib.check(_lib.lib().r2dm_attention(qkv.data_ptr(), out.data_ptr(), B, C, heads, N, _st(qkv)))
+    torch.cuda.synchronize()
+    return out
+
+
+def time_embedding(cond, freqs, w1, b1, w2, b2):
+    B, T, base = cond.shape[0], w1.shape[0], w1.shape[1]
+    act = torch.empty(B, T, device=cond.device)
+    _lib.check(_lib.lib().r2dm_time_embedding(cond.data_ptr(), freqs.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                             w2.data_ptr(), b2.data_ptr(), act.data_ptr(), B, base, T, _st(cond)))
+    torch.cuda.synchronize()
+    return act

@@ -1,0 +1,166 @@
+"""CPU tests: host logic, state-dict compatibility, the C-ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN_RES, ROOT, synthetic_ckpt
+
+
+def test_library_exports_every_declared_symbol():
+    from r2dm_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "r2dm_hip.h")).read()
+    declared = set(re.findall(r"\b(r2dm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"r2dm_handle"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.r2dm_version()
+
+
+def test_engine_plan_and_blob_layout_without_gpu():
+    """Handle creation, tensor table and workspace sizing are host-only."""
+    from r2dm_amd import _lib, synthetic
+    from r2dm_amd.unet import _Engine
+
+    g = synthetic.geometry_from_cfg(synthetic.default_cfg_dict())
+    eng = _Engine(g, 8)
+    slots = list(eng.slots())
+    keys = [k for _, k, _ in slots]
+    sd = synthetic.synthetic_state_dict(g, prefix="")
+    fixed = {k for k in sd if k.endswith(".kernel") or k in ("coords", "coords_encoding.freqs", "coords_encoding.phase")}
+    assert set(keys) == (set(sd) - fixed) | {"__cenc", "__sin_freqs"}
+    for _, k, n in slots:
+        if not k.startswith("__"):
+            assert sd[k].numel() == n, k
+    assert sum(n for _, k, n in slots if not k.startswith("__")) >= 31_099_650 - 2 * 64 * 1024 - 64
+    assert 120e6 < eng.blob_bytes() < 160e6  # ~31 M floats + padding
+    L = _lib.lib()
+    w1, w8 = L.r2dm_workspace_bytes(eng.h, 1), L.r2dm_workspace_bytes(eng.h, 8)
+    assert 0 < w1 < w8 < 4e9 and abs(w8 / w1 - 8) < 1.0
+
+
+def test_bad_geometry_is_refused():
+    from r2dm_amd import _lib
+    from r2dm_amd.spec import UNetGeometry
+    from r2dm_amd.unet import _Engine
+
+    with pytest.raises(_lib.R2DMError, match="attention"):
+        _Engine(UNetGeometry.make(2, (16, 128), base_channels=8), 1)  # head_dim 8 / 4: unsupported
+    with pytest.raises(_lib.R2DMError):
+        _Engine(UNetGeometry.make(2, (20, 100), base_channels=64), 1)
+
+
+def test_state_dict_layout_matches_reference_listing():
+    """268 keys, the reference's names; strict load both ways."""
+    import r2dm_amd
+
+    ck = synthetic_ckpt(resolution=GOLDEN_RES)
+    ddpm, lidar, cfg = r2dm_amd.setup_model(ck, device="cpu", show_info=False)
+    sd = ddpm.state_dict()
+    assert len(sd) == 268 and list(sd)[0] == "_dummy"
+    assert set(sd) == set(ck["ema_weights"])
+    for k, v in sd.items():
+        assert torch.equal(v, ck["ema_weights"][k]), k
+    assert sum(p.numel() for p in r2dm_amd.setup_model(synthetic_ckpt(), show_info=False)[0].parameters()) == 31_099_650
+    assert ddpm.sampling_shape == (2, *GOLDEN_RES) and ddpm.device.type == "cpu"
+    assert ddpm.model.coords.shape == (1, 2, *GOLDEN_RES)
+    bad = dict(ck["ema_weights"])
+    bad.pop("model.out_conv.bias")
+    with pytest.raises(RuntimeError):
+        ddpm.load_state_dict(bad)
+    assert lidar.ray_angles.shape == (1, 2, *GOLDEN_RES) and cfg.data.max_depth == 80.0
+
+
+def test_no_cpu_fallback():
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(resolution=GOLDEN_RES), device="cpu", show_info=False)
+    with pytest.raises(R2DMError, match="no CPU fallback"):
+        ddpm.sample(batch_size=1, num_steps=1, progress=False)
+    with pytest.raises(R2DMError, match="no CPU fallback"):
+        ddpm.model(torch.zeros(1, 2, *GOLDEN_RES), torch.zeros(1))
+    with pytest.raises(NotImplementedError):
+        ddpm(torch.zeros(1, 2, *GOLDEN_RES))  # training loss is out of scope
+
+
+def test_coefficient_tables_match_reference_schedule(golden):
+    """Host-side schedule scalars are bit-identical to what the reference computes for batch 1 (golden 'schedule')."""
+    from r2dm_amd import diffusion as D
+
+    class Stub(torch.nn.Module):
+        resolution, in_channels = GOLDEN_RES, 2
+
+    d = D.ContinuousTimeGaussianDiffusion(Stub())
+    g = golden("schedule")
+    # the product evaluates every row on 1-element tensors (scalar libm path), like the reference's sample()
+    # does for batch 1; the golden schedule was captured the same way -> bit-identical
+    for S in (8, 32, 256):
+        t = torch.linspace(1.0, 0.0, S + 1)
+        cond, coef, mode = d._coefficients(t[:-1], t[1:], "ddpm", 0.0)
+        assert torch.equal(cond, g[f"lam{S}"][:-1])
+        assert torch.equal(coef[:, 0], g[f"alpha{S}"][:-1]) and torch.equal(coef[:, 1], g[f"sigma{S}"][:-1])
+        assert torch.equal(coef[:, 2], g[f"alpha{S}"][1:]) and torch.equal(coef[:, 3], g[f"sigma{S}"][1:])
+        assert torch.equal(coef[:, 4], g[f"c{S}"]) and mode == 0
+        assert torch.equal(coef[:, 5], torch.cat([g[f"sigma{S}"][i + 1:i + 2] * g[f"c{S}"][i:i + 1].sqrt() for i in range(S)]))
+        # and it does not depend on how many rows are evaluated together
+        c1, k1, _ = d._coefficients(t[3:4], t[4:5], "ddpm", 0.0)
+        assert torch.equal(c1, cond[3:4]) and torch.equal(k1, coef[3:4])
+    with pytest.raises(ValueError, match="invalid mode"):
+        d._coefficients(t[:-1], t[1:], "euler", 0.0)
+    with pytest.raises(ValueError):
+        D.ContinuousTimeGaussianDiffusion(Stub(), noise_schedule="nope")
+    bad = D.ContinuousTimeGaussianDiffusion(Stub(), prediction_type="score")
+    with pytest.raises(ValueError, match="invalid objective"):
+        bad.sample(1, 1, progress=False)
+
+
+def test_rng_draw_shapes_and_order():
+    """randn semantics of base.py:71-94: None / Generator / list of Generators (len == B)."""
+    from r2dm_amd import diffusion as D, setup_rng
+
+    class Stub(torch.nn.Module):
+        resolution, in_channels = (4, 8), 2
+
+    d = D.ContinuousTimeGaussianDiffusion(Stub())
+    gens = setup_rng([5, 6], "cpu")
+    a = d.randn(2, 2, 4, 8, rng=gens)
+    assert torch.equal(a[1], torch.randn(2, 4, 8, generator=torch.Generator().manual_seed(6)))
+    b = d.randn(2, 2, 4, 8, rng=torch.Generator().manual_seed(5))
+    assert torch.equal(b, torch.randn(2, 2, 4, 8, generator=torch.Generator().manual_seed(5)))
+    with pytest.raises(AssertionError):
+        d.randn(3, 2, 4, 8, rng=gens)
+    with pytest.raises(ValueError):
+        d.randn(2, 2, rng="seed")
+
+
+def test_config_roundtrip_and_validation():
+    from r2dm_amd.option import Config
+
+    c = Config(**synthetic_ckpt(resolution=GOLDEN_RES)["cfg"])
+    assert c.data.resolution == GOLDEN_RES and c.model.coords_encoding == "fourier_features"
+    assert c.data.min_depth == 1.45 and c.diffusion.timestep_type == "continuous"
+    with pytest.raises(TypeError):
+        Config(model={"no_such_field": 1})
+    with pytest.raises(ValueError):
+        Config(diffusion={"prediction_type": "score"})
+
+
+def test_lidar_utility_cpu_members(golden):
+    """The non-fused LiDARUtility members are device-agnostic torch expressions (not the hot path)."""
+    from r2dm_amd.lidar import LiDARUtility
+
+    g = golden("lidar")
+    lu = LiDARUtility(GOLDEN_RES, "log_depth", 1.45, 80.0, ray_angles=g["ray_angles"])
+    s = lu.denormalize(g["x"])
+    depth = lu.revert_depth(s[:, [0]])
+    y = torch.cat([depth, lu.to_xyz(depth), s[:, [1]]], 1)
+    assert (y - g["y"]).abs().max() < 1e-5
+    back = lu.convert_depth(depth)
+    m = lu.get_mask(depth)
+    assert ((back - s[:, [0]]) * m).abs().max() < 1e-5

@@ -62,6 +62,7 @@ struct ConvParams {
     int taps;            // 9 or 1
     int co_tile;         // 32 / 64 / 128 (must match the packing)
     int prologue;        // Prologue
+    unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
 int conv_pick_co_tile(int Cout, int taps, long pixels_times_batch);
 int conv_cin_pad(int Cin, int taps, int co_tile);

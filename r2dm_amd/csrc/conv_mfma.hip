@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     L /= nTw;
     const int th = L % nTh;
     const int b = L / nTh;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (p.prof) t0 = __builtin_amdgcn_s_memtime();
 
     // ---- per-thread staging map: element e = tid + i*256 of the [CK][XR][XS] halo tile ----
     int pk[C::NXT];  // sign: outside the image / past the tile; bits 24..28: channel in chunk; low 24: y*W+x
@@ -89,10 +91,6 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
         pk[i] = ok ? ((cl << 24) | (gr * W + gc)) : (int)0x80000000;
     }
 
-    if (PRO != PRO_NONE) {  // folded GroupNorm affine of this sample, all input channels
-        for (int c = tid; c < p.Cin; c += 256) affs[c] = p.aff[(size_t)b * p.Cin + c];
-    }
-
     const float* wsrc = p.w + (size_t)cot * p.CinPad * TAPS * CO_T;
     const float* xb0 = p.x.p0 + b * p.x.bs0;
     const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
@@ -107,8 +105,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
         const f32x4* w4 = reinterpret_cast<const f32x4*>(wsrc + (size_t)ci0 * TAPS * CO_T);
 #pragma unroll
         for (int i = 0; i < C::NWT; ++i) {
-            const int e = tid + i * 256;
-            if (C::NW4 % 256 == 0 || e < C::NW4) wv[i] = w4[e];
+            const int e = tid + i * 256;  // clamped, never predicated: a predicated load becomes an exec-masked
+            wv[i] = w4[e < C::NW4 ? e : C::NW4 - 1];  // branch with a vmcnt wait in front of it
         }
         // activations: branch-free loads (invalid elements read a safe address and are zeroed at store)
         if (ci0 + CK <= c0 || ci0 >= c0) {
@@ -176,9 +174,14 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
 
     const int nchunks = p.CinPad / CK;
     stage_load(0);
-    if (PRO != PRO_NONE) __syncthreads();  // affs visible
+    if (PRO != PRO_NONE) {  // folded GroupNorm affine of this sample (all input channels) -> LDS; its HBM/L2 round
+        // trip overlaps the first chunk's loads issued just above
+        for (int c = tid; c < p.Cin; c += 256) affs[c] = p.aff[(size_t)b * p.Cin + c];
+        __syncthreads();
+    }
     stage_store(smem, 0);
     __syncthreads();
+    if (p.prof) t1 = __builtin_amdgcn_s_memtime();
 
     for (int k = 0; k < nchunks; ++k) {
         const float* buf = smem + (k & 1) * C::BUF;
@@ -225,39 +228,66 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     // share one offset VGPR.  All loads of a 32x32 tile (bias, residual) are issued before its first store: the
     // output may alias the residual as far as the compiler knows, and load-after-store would otherwise serialise
     // an L2 round trip per element.
+    if (p.prof) t2 = __builtin_amdgcn_s_memtime();
     const float sc = p.scale ? *p.scale : 1.0f;
     const int co_u = cot * CO_T + wave_co * (CO_T / WCO);  // wave-uniform first output channel
     float* yu = p.y + b * p.y_bs + (long)co_u * HW;
     const float* ru = p.res ? p.res + b * p.res_bs + (long)co_u * HW : nullptr;
     const float* bu = p.bias + co_u;
+    // EPI_N pixel segments are processed per pass: all their residual loads are in flight together.
+    constexpr int EPI_N = (C::MR * C::NR * 16 <= 64) ? C::NR : (C::NR / 2 > 0 ? C::NR / 2 : 1);
+    float bv[C::MR][16];
 #pragma unroll
-    for (int n = 0; n < C::NR; ++n) {
-        const int s = wave_px * C::NR + n;
-        const int gr = th * TH + s / C::SEGW;
-        const int gc = tw * TW + (s % C::SEGW) * 32 + l31;
-        const bool px_ok = gr < H && gc < W;
-        const int loff = (px_ok ? gr * W + gc : 0) + 4 * hi * HW;
+    for (int m = 0; m < C::MR; ++m)
 #pragma unroll
-        for (int m = 0; m < C::MR; ++m) {
-            float bv[16], rv[16];
+        for (int r = 0; r < 16; ++r) {
+            const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+            bv[m][r] = (bu + cu)[co_u + cu + 4 * hi < p.Cout ? 4 * hi : 0];
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = co_u + cu + 4 * hi < p.Cout;
-                bv[r] = (bu + cu)[ok ? 4 * hi : 0];
-                if (ru) rv[r] = (ru + (long)cu * HW)[ok ? loff : 0];
-            }
+    for (int n0 = 0; n0 < C::NR; n0 += EPI_N) {
+        int loff[EPI_N];
+        bool px_ok[EPI_N];
+        float rv[EPI_N][C::MR][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
-                float v = acc[m][n][r];
-                if (ACC2) v += acc2[m][n][r];
-                v += bv[r];
-                if (ru) v = rv[r] + v;
-                if (p.scale) v *= sc;
-                if (px_ok && co_u + cu + 4 * hi < p.Cout) (yu + (long)cu * HW)[loff] = v;
+        for (int j = 0; j < EPI_N; ++j) {
+            const int s = wave_px * C::NR + n0 + j;
+            const int gr = th * TH + s / C::SEGW;
+            const int gc = tw * TW + (s % C::SEGW) * 32 + l31;
+            px_ok[j] = gr < H && gc < W;
+            loff[j] = (px_ok[j] ? gr * W + gc : 0) + 4 * hi * HW;
+            if (ru) {
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+                        rv[j][m][r] = (ru + (long)cu * HW)[co_u + cu + 4 * hi < p.Cout ? loff[j] : 0];
+                    }
             }
         }
+#pragma unroll
+        for (int j = 0; j < EPI_N; ++j)
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[m][n0 + j][r];
+                    if (ACC2) v += acc2[m][n0 + j][r];
+                    v += bv[m][r];
+                    if (ru) v = rv[j][m][r] + v;
+                    if (p.scale) v *= sc;
+                    if (px_ok[j] && co_u + cu + 4 * hi < p.Cout) (yu + (long)cu * HW)[loff[j]] = v;
+                }
+    }
+    if (p.prof && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.prof + (size_t)blockIdx.x * 4;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+        o[3] = __builtin_amdgcn_s_memtime();
     }
 }
 

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -600,6 +601,8 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.Cin = cin;
     p.Cout = cout;
     p.prologue = prologue;
+    // perf probe (scripts/conv_phases.py): per-block s_memtime stamps into a caller-provided device buffer
+    if (const char* e = getenv("R2DM_CONV_PROF_PTR")) p.prof = (unsigned long long*)strtoull(e, nullptr, 0);
     HIP_TRY(launch_conv(p, st));
     return 0;
 }

@@ -111,10 +111,24 @@ def main():
     assert torch.isfinite(out).all()
     gpu_ms = ev0.elapsed_time(ev1)
 
+    # Dominant kernel (conv_mfma_kernel, ~96 % of the FLOPs and of the step time): an extra, untimed pass of a few
+    # steps with every conv launch bracketed by HIP events on the sampling stream (r2dm_profile_*).
+    conv = None
+    if rank == 0:
+        ddpm.model.profile_convs(True)
+        psteps = min(args.steps, 4)
+        run(psteps)
+        conv_ms, conv_flop, conv_n = ddpm.model.read_conv_profile()
+        ddpm.model.profile_convs(False)
+        conv = {"kernel": "conv_mfma_kernel (fp32 MFMA implicit-GEMM 3x3/1x1 conv, fused GN+SiLU prologue / residual epilogue)",
+                "launches": conv_n, "launches_per_step": conv_n // psteps, "avg_launch_us": conv_ms * 1e3 / conv_n,
+                "algorithmic_gflop_per_launch": conv_flop / conv_n / 1e9, "tflops": conv_flop / conv_ms / 1e9,
+                "ms_per_step": conv_ms / psteps}
+
     if rank == 0:
         sec_per_step = dt / args.steps
         value = world * B / (sec_per_step * SAMPLER_STEPS)
-        flops = B * FLOP_PER_IMAGE_STEP / (gpu_ms / 1e3 / args.steps)
+        step_flops = B * FLOP_PER_IMAGE_STEP / (gpu_ms / 1e3 / args.steps)
         line = {
             "metric": "range-images/sec (64x1024, 256-step DDPM)", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
@@ -123,10 +137,13 @@ def main():
                                    "timed = one sample() call of --steps reverse steps, value scaled to 256 steps",
                        "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
                        "sampler_steps": SAMPLER_STEPS, "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
-            "roofline": {"bound": "mfma", "achieved": flops / 1e12, "peak": PEAK_FP32 / 1e12, "unit": "TFLOP/s",
-                         "frac": flops / PEAK_FP32, "traffic": None,
-                         "note": "whole reverse step (U-Net forward + posterior): algorithmic 234.52 GFLOP/image-step x batch / "
-                                 "HIP-event time per step on the sampling stream; fp32 MFMA peak"},
+            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_FP32 / 1e12, "unit": "TFLOP/s",
+                         "frac": conv["tflops"] * 1e12 / PEAK_FP32, "traffic": None,
+                         "dominant_kernel": conv,
+                         "whole_step": {"achieved": step_flops / 1e12, "frac": step_flops / PEAK_FP32,
+                                        "note": "234.52 GFLOP/image-step x batch / HIP-event time of the timed sample() call"},
+                         "note": "achieved = sum of algorithmic conv FLOPs / sum of conv kernel time (HIP events on the sampling "
+                                 "stream, rank 0); peak = MI355X fp32 MFMA = fp32 vector peak; traffic: see profiles/ (PMC pass)"},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ck)

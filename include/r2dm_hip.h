@@ -77,6 +77,13 @@ size_t r2dm_workspace_bytes(const r2dm_handle* h, int32_t batch);
 int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t batch,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* -- measurement aid (bench.py): when enabled, every launch of the dominant kernel class -- the MFMA
+ *    convolution, conv_mfma_kernel, 60 launches per forward -- is bracketed by hipEvents recorded on the
+ *    caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed
+ *    ALGORITHMIC flops (2*B*Cout*Cin*k*k*H*W per launch) and the number of launches, then resets. */
+int r2dm_profile_enable(r2dm_handle* h, int32_t on);
+int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_t* launches);
+
 /* -- posterior update: replaces the elementwise tail of p_step
  *    (continuous_time.py:208-229, discrete_time.py:140-177).  coef is (B,8) host-computed scalars,
  *    see r2dm_amd/diffusion.py for the slot meaning per mode.

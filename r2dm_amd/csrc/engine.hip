@@ -93,6 +93,11 @@ struct r2dm_handle {
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
     int ada_rows = 0;
     std::map<int, size_t> ws_cache;
+    // optional in-stream timing of the dominant kernel class (r2dm_profile_*)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;  // pairs
+    size_t prof_used = 0;
+    double prof_flop = 0.0;
 
     size_t take(size_t floats) {
         const size_t off = blob_floats;
@@ -330,7 +335,25 @@ struct Ctx {
             p.taps = L.taps;
             p.co_tile = L.co_tile;
             p.prologue = pro;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->prof_on) {
+                if (h->prof_used + 2 > h->prof_ev.size()) {
+                    hipEvent_t a, c;
+                    if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&c) == hipSuccess) {
+                        h->prof_ev.push_back(a);
+                        h->prof_ev.push_back(c);
+                    }
+                }
+                if (h->prof_used + 2 <= h->prof_ev.size()) {
+                    e0 = h->prof_ev[h->prof_used];
+                    e1 = h->prof_ev[h->prof_used + 1];
+                    h->prof_used += 2;
+                    h->prof_flop += 2.0 * B * (double)L.cout * L.cin * L.taps * H * W;
+                    (void)hipEventRecord(e0, st);
+                }
+            }
             note(launch_conv(p, st), "conv");
+            if (e1) (void)hipEventRecord(e1, st);
         }
         return y;
     }
@@ -493,7 +516,11 @@ int r2dm_create(r2dm_handle** out, const r2dm_config* cfg) {
     return 0;
 }
 
-void r2dm_destroy(r2dm_handle* h) { delete h; }
+void r2dm_destroy(r2dm_handle* h) {
+    if (!h) return;
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    delete h;
+}
 
 int64_t r2dm_num_tensors(const r2dm_handle* h) { return h ? (int64_t)h->slots.size() : 0; }
 
@@ -565,6 +592,31 @@ int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t
                            float min_depth, float max_depth, void* stream) {
     if (!x || !ang || !out) return fail(1, "null argument");
     HIP_TRY(launch_lidar_postprocess(x, ang, out, B, H, W, min_depth, max_depth, (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_profile_enable(r2dm_handle* h, int32_t on) {
+    if (!h) return fail(1, "null argument");
+    h->prof_on = on != 0;
+    h->prof_used = 0;
+    h->prof_flop = 0.0;
+    return 0;
+}
+
+int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_t* launches) {
+    if (!h || !conv_ms || !conv_flop || !launches) return fail(1, "null argument");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(h->prof_ev[i + 1]));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]));
+        ms += t;
+    }
+    *conv_ms = ms;
+    *conv_flop = h->prof_flop;
+    *launches = (int64_t)(h->prof_used / 2);
+    h->prof_used = 0;
+    h->prof_flop = 0.0;
     return 0;
 }
 

@@ -254,6 +254,19 @@ class EfficientUNet(nn.Module):
             self._engine = _Engine(self.geometry, self.max_batch)
         return self._engine.blob_bytes()
 
+    # -- measurement aid ---------------------------------------------------------------------------
+    def profile_convs(self, on: bool):
+        """Bracket every MFMA-convolution launch with HIP events on the sampling stream (bench.py)."""
+        if self._engine is None:
+            raise _lib.R2DMError("run a forward pass first")
+        _lib.check(_lib.lib().r2dm_profile_enable(self._engine.h, int(on)))
+
+    def read_conv_profile(self):
+        """-> (kernel milliseconds, algorithmic flops, launches) since profile_convs(True); resets."""
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(_lib.lib().r2dm_profile_read(self._engine.h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
+        return ms.value, fl.value, n.value
+
     # -- the hot path ----------------------------------------------------------------------------
     def forward(self, images: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
         _lib.require_gpu(images, "images")

@@ -15,8 +15,9 @@
 //
 // Block = 256 threads = 4 waves, tile = CO_T output channels x (TH x TW) pixels, K walked in chunks
 // of CK input channels through a double-buffered LDS stage (one barrier per chunk):
-//   * activations: (TH+2)x(TW+2) halo tile per channel (wrap in W, zero in H), global -> registers
-//     (issued before the chunk's MFMAs) -> prologue -> LDS (after them);
+//   * activations: (TH+2) x (TW+2) halo tile per channel (wrap in W, zero in H): the 16-byte-aligned interior as
+//     float4 pieces + two halo scalars, global -> registers (issued before the chunk's MFMAs) -> prologue -> LDS
+//     (after them); all addressing is precomputed once per block;
 //   * weights: the chunk's packed [CK][taps][CO_T] slab is contiguous in HBM: 16-byte loads -> registers
 //     -> ds_write_b128, same timing as the activations;
 // Accuracy: with ACC2 the accumulators are flushed into a second register set every 64 input
@@ -29,15 +30,19 @@ template <int TAPS, int CO_T, int TH, int TW, int WCO, int WPX, int CK>
 struct ConvCfg {
     static constexpr int HALO = TAPS == 9 ? 1 : 0;
     static constexpr int XR = TH + 2 * HALO;
-    static constexpr int XS = TW + 2 * HALO;
+    // LDS row: [3 pad][left halo][TW interior, 16-byte aligned][right halo][3 pad]  (no halo/pad for 1x1)
+    static constexpr int XI = HALO ? 4 : 0;              // index of the first interior column
+    static constexpr int XS = TW + (HALO ? 8 : 0);
     static constexpr int XPLANE = XR * XS;
-    static constexpr int NX = CK * XPLANE;
-    static constexpr int NX_PAD = (NX + 3) & ~3;
+    static constexpr int NX = CK * XPLANE;               // multiple of 4
+    static constexpr int NQ = CK * XR * (TW / 4);        // interior 16-byte pieces per chunk
+    static constexpr int NQT = (NQ + 255) / 256;
+    static constexpr int NH = HALO ? CK * XR * 2 : 0;    // halo scalars per chunk
+    static constexpr int NHT = (NH + 255) / 256;
     static constexpr int NW = CK * TAPS * CO_T;
     static constexpr int NW4 = NW / 4;
     static constexpr int NWT = (NW4 + 255) / 256;
-    static constexpr int BUF = NX_PAD + NW;
-    static constexpr int NXT = (NX + 255) / 256;
+    static constexpr int BUF = NX + NW;
     static constexpr int MR = CO_T / WCO / 32;
     static constexpr int SEGW = TW / 32;
     static constexpr int NSEG = TH * SEGW;
@@ -45,9 +50,10 @@ struct ConvCfg {
     static constexpr int NSTEP = (CK / 2) * TAPS;
     static constexpr int FLUSH = 64 / CK;  // chunks per accumulator flush (ACC2)
     static_assert(WCO * WPX == 4, "4 waves per block");
-    static_assert(MR >= 1 && NR >= 1 && CK % 2 == 0 && NW % 4 == 0 && 64 % CK == 0, "tile shape");
-    static constexpr size_t lds_bytes(int cin, bool pro) {
-        return (2 * (size_t)BUF + (pro ? 2 * (size_t)((cin + 1) & ~1) : 0)) * sizeof(float);
+    static_assert(MR >= 1 && NR >= 1 && CK % 2 == 0 && NW % 4 == 0 && 64 % CK == 0 && TW % 4 == 0, "tile shape");
+    static_assert(NHT <= 1 && NQT <= 7 && CK <= 16, "staging map packing");
+    static constexpr size_t lds_bytes(int cin_pad, bool pro) {
+        return (2 * (size_t)BUF + (pro ? 2 * (size_t)((cin_pad + 1) & ~1) : 0)) * sizeof(float);
     }
 };
 
@@ -76,26 +82,51 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (p.prof) t0 = __builtin_amdgcn_s_memtime();
 
-    // ---- per-thread staging map: element e = tid + i*256 of the [CK][XR][XS] halo tile ----
-    int pk[C::NXT];  // sign: outside the image / past the tile; bits 24..28: channel in chunk; low 24: y*W+x
+    // ---- per-thread staging map (computed once per block) ----
+    // The interior of every staged row is TW contiguous, 16-byte aligned floats in HBM and in LDS: it moves as
+    // float4 pieces (global_load_dwordx4 -> prologue -> ds_write_b128); only the two halo columns are scalars.
+    // Columns wrap modulo W (azimuth is periodic; also covers tiles overhanging a narrow image), rows outside
+    // [0,H) are zero padding.  Piece offsets / validity / LDS positions are per-thread constants, so per chunk the
+    // staging costs one load + one write instruction per piece and no address arithmetic (fp32 MFMA and VALU
+    // share one execution pipe on gfx950 -- scripts/mfma_valu_overlap.hip -- so every VALU op is paid in full).
+    int qoff[C::NQT], qlds[C::NQT];  // global float offset within the chunk (0 if invalid) / LDS float offset
+    int hoff = 0, hlds = 0;
+    unsigned okbits = 0;             // bit j: piece j valid; bit 8: halo valid
+    unsigned clbits = 0;             // 4 bits per piece (+ halo in bits 28..31): channel within the chunk
 #pragma unroll
-    for (int i = 0; i < C::NXT; ++i) {
-        const int e = tid + i * 256;
-        const int cl = e / C::XPLANE, rem = e % C::XPLANE;
-        const int r = rem / C::XS, c = rem % C::XS;
+    for (int j = 0; j < C::NQT; ++j) {
+        int q = tid + j * 256;
+        q = q < C::NQ ? q : C::NQ - 1;  // surplus threads redo the last piece (same data, same place)
+        const int cl = q / (C::XR * (TW / 4)), r = (q / (TW / 4)) % C::XR, c4 = q % (TW / 4);
         const int gr = th * TH + r - C::HALO;
-        int gc = tw * TW + c - C::HALO;
+        int gc = tw * TW + c4 * 4;
+        while (gc >= W) gc -= W;
+        const bool ok = gr >= 0 && gr < H;
+        qoff[j] = ok ? cl * HW + gr * W + gc : 0;
+        qlds[j] = cl * C::XPLANE + r * C::XS + C::XI + c4 * 4;
+        okbits |= ok ? (1u << j) : 0u;
+        clbits |= (unsigned)cl << (4 * j);
+    }
+    if (C::NHT) {
+        int hq = tid < C::NH ? tid : C::NH - 1;
+        const int cl = hq / (C::XR * 2), r = (hq / 2) % C::XR, side = hq & 1;
+        const int gr = th * TH + r - C::HALO;
+        int gc = side ? tw * TW + TW : tw * TW - 1;
         if (gc < 0) gc += W;
         while (gc >= W) gc -= W;
-        const bool ok = (e < C::NX) && gr >= 0 && gr < H;
-        pk[i] = ok ? ((cl << 24) | (gr * W + gc)) : (int)0x80000000;
+        const bool ok = gr >= 0 && gr < H;
+        hoff = ok ? cl * HW + gr * W + gc : 0;
+        hlds = cl * C::XPLANE + r * C::XS + (side ? C::XI + TW : C::XI - 1);
+        okbits |= ok ? (1u << 8) : 0u;
+        clbits |= (unsigned)cl << 28;
     }
 
     const float* wsrc = p.w + (size_t)cot * p.CinPad * TAPS * CO_T;
     const float* xb0 = p.x.p0 + b * p.x.bs0;
     const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
     const int c0 = p.x.c0;
-    float xv[C::NXT];
+    f32x4 xq[C::NQT];
+    float xh = 0.f;
     f32x4 wv[C::NWT];
 
     auto stage_load = [&](int ci0) {
@@ -108,42 +139,67 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
             const int e = tid + i * 256;  // clamped, never predicated: a predicated load becomes an exec-masked
             wv[i] = w4[e < C::NW4 ? e : C::NW4 - 1];  // branch with a vmcnt wait in front of it
         }
-        // activations: branch-free loads (invalid elements read a safe address and are zeroed at store)
-        if (ci0 + CK <= c0 || ci0 >= c0) {
+        const bool whole = ci0 + CK <= p.Cin && (ci0 + CK <= c0 || ci0 >= c0);
+        if (whole) {  // (wave-uniform base of the chunk's first channel) + (precomputed per-lane offset)
             const float* base = ci0 >= c0 ? xb1 + (long)(ci0 - c0) * HW : xb0 + (long)ci0 * HW;
 #pragma unroll
-            for (int i = 0; i < C::NXT; ++i) {
-                const int cl = (pk[i] >> 24) & 0x1f;
-                const bool ok = pk[i] >= 0 && ci0 + cl < p.Cin;
-                const int off = cl * HW + (pk[i] & 0xffffff);
-                xv[i] = base[ok ? off : 0];
-            }
-        } else {  // the chunk straddles the concat seam (only in_conv: 2 image + coordinate channels)
+            for (int j = 0; j < C::NQT; ++j) xq[j] = *reinterpret_cast<const f32x4*>(base + qoff[j]);
+            if (C::NHT) xh = base[hoff];
+        } else {  // last partial chunk (Cin % CK != 0) or a chunk straddling the concat seam (in_conv only)
 #pragma unroll
-            for (int i = 0; i < C::NXT; ++i) {
-                const int ci = ci0 + ((pk[i] >> 24) & 0x1f);
-                const bool ok = pk[i] >= 0 && ci < p.Cin;
+            for (int j = 0; j < C::NQT; ++j) {
+                const int cl = (clbits >> (4 * j)) & 15, ci = ci0 + cl;
+                const bool ok = ((okbits >> j) & 1) && ci < p.Cin;
                 const float* pl = ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW;
-                xv[i] = ok ? pl[pk[i] & 0xffffff] : 0.f;
+                xq[j] = *reinterpret_cast<const f32x4*>(pl + (ok ? qoff[j] - cl * HW : 0));
+            }
+            if (C::NHT) {
+                const int cl = clbits >> 28, ci = ci0 + cl;
+                const bool ok = ((okbits >> 8) & 1) && ci < p.Cin;
+                const float* pl = ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW;
+                xh = pl[ok ? hoff - cl * HW : 0];
             }
         }
     };
     auto stage_store = [&](float* buf, int ci0) {
+        // Three independent batches -- table reads, transforms, LDS writes -- instead of one read/transform/write
+        // chain per piece: the table lives in the same LDS array as the staging buffers, so the compiler must
+        // keep every table read behind the previous write, and each chain would cost a full LDS latency.
+        const bool whole = ci0 + CK <= p.Cin;
+        float2 ad[C::NQT + 1];
+        if (PRO != PRO_NONE) {
 #pragma unroll
-        for (int i = 0; i < C::NXT; ++i) {
-            const int e = tid + i * 256;
-            const int ci = ci0 + ((pk[i] >> 24) & 0x1f);
-            const bool ok = pk[i] >= 0 && ci < p.Cin;
-            float v = xv[i];
+            for (int j = 0; j < C::NQT; ++j) ad[j] = affs[ci0 + (int)((clbits >> (4 * j)) & 15)];  // zero-filled to CinPad
+            if (C::NHT) ad[C::NQT] = affs[ci0 + (int)(clbits >> 28)];
+        }
+#pragma unroll
+        for (int j = 0; j < C::NQT; ++j) {
+            bool ok = (okbits >> j) & 1;
+            if (!whole) ok = ok && ci0 + (int)((clbits >> (4 * j)) & 15) < p.Cin;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = xq[j][e];
+                if (PRO != PRO_NONE) {
+                    v = v * ad[j].x + ad[j].y;
+                    if (PRO == PRO_AFFINE_SILU) v = silu_f(v);
+                }
+                xq[j][e] = ok ? v : 0.f;  // zero padding applies to the *activated* tensor
+            }
+        }
+        if (C::NHT) {
+            bool ok = (okbits >> 8) & 1;
+            if (!whole) ok = ok && ci0 + (int)(clbits >> 28) < p.Cin;
+            float v = xh;
             if (PRO != PRO_NONE) {
-                const float2 ad = affs[ok ? ci : 0];
-                v = v * ad.x + ad.y;
+                v = v * ad[C::NQT].x + ad[C::NQT].y;
                 if (PRO == PRO_AFFINE_SILU) v = silu_f(v);
             }
-            v = ok ? v : 0.f;  // zero padding applies to the *activated* tensor
-            if (C::NX % 256 == 0 || e < C::NX) buf[e] = v;
+            xh = ok ? v : 0.f;
         }
-        f32x4* w4 = reinterpret_cast<f32x4*>(buf + C::NX_PAD);
+#pragma unroll
+        for (int j = 0; j < C::NQT; ++j) *reinterpret_cast<f32x4*>(buf + qlds[j]) = xq[j];
+        if (C::NHT) buf[hlds] = xh;
+        f32x4* w4 = reinterpret_cast<f32x4*>(buf + C::NX);
 #pragma unroll
         for (int i = 0; i < C::NWT; ++i) {
             const int e = tid + i * 256;
@@ -156,9 +212,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
     for (int n = 0; n < C::NR; ++n) {
         const int s = wave_px * C::NR + n;
-        xoff[n] = hi * C::XPLANE + (s / C::SEGW) * C::XS + (s % C::SEGW) * 32 + l31;
+        xoff[n] = hi * C::XPLANE + (s / C::SEGW) * C::XS + (C::XI - C::HALO) + (s % C::SEGW) * 32 + l31;
     }
-    const int woff = C::NX_PAD + hi * TAPS * CO_T + wave_co * (CO_T / WCO) + l31;
+    const int woff = C::NX + hi * TAPS * CO_T + wave_co * (CO_T / WCO) + l31;
 
     f32x16 acc[C::MR][C::NR];
     f32x16 acc2[ACC2 ? C::MR : 1][ACC2 ? C::NR : 1];
@@ -176,7 +232,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     stage_load(0);
     if (PRO != PRO_NONE) {  // folded GroupNorm affine of this sample (all input channels) -> LDS; its HBM/L2 round
         // trip overlaps the first chunk's loads issued just above
-        for (int c = tid; c < p.Cin; c += 256) affs[c] = p.aff[(size_t)b * p.Cin + c];
+        for (int c = tid; c < p.CinPad; c += 256) affs[c] = c < p.Cin ? p.aff[(size_t)b * p.Cin + c] : make_float2(0.f, 0.f);
         __syncthreads();
     }
     stage_store(smem, 0);
@@ -343,7 +399,7 @@ template <int TAPS, int CO_T, int WCO, int WPX, int CK, int PRO, bool ACC2, int 
 static hipError_t launch_variant(const ConvParams& p, hipStream_t s) {
     using C = ConvCfg<TAPS, CO_T, 4, 64, WCO, WPX, CK>;
     auto kern = conv_mfma_kernel<TAPS, CO_T, 4, 64, WCO, WPX, CK, PRO, ACC2, OCC>;
-    const size_t lds = C::lds_bytes(p.Cin, PRO != PRO_NONE);
+    const size_t lds = C::lds_bytes(p.CinPad, PRO != PRO_NONE);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -370,7 +426,8 @@ static hipError_t launch_pro(const ConvParams& p, hipStream_t s) {
 hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.CinPad != conv_cin_pad(p.Cin, p.taps, p.co_tile)) return hipErrorInvalidValue;
-    if (p.H * (long)p.W >= (1 << 24)) return hipErrorInvalidValue;
+    if (p.H * (long)p.W * 16 >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit element offsets within a chunk
+    if (p.W % 4) return hipErrorInvalidValue;                              // 16-byte row pieces
     if (p.taps == 9) {
         if (p.co_tile == 128) return launch_pro<9, 128, 2, 2, kCK3_128, false, 2>(p, s);
         if (p.co_tile == 64) {

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     L /= nTw;
     const int th = L % nTh;
     const int b = L / nTh;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, ta = 0, tb = 0, s_load = 0, s_mfma = 0, s_bar = 0;  // perf probe
     if (p.prof) t0 = __builtin_amdgcn_s_memtime();
 
     // ---- per-thread staging map (computed once per block) ----
@@ -239,14 +239,56 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     __syncthreads();
     if (p.prof) t1 = __builtin_amdgcn_s_memtime();
 
+    // Staging tasks of the NEXT chunk (registers -> prologue -> LDS), one per K-step in the second half of the MFMA
+    // sequence: their dependent chains (table read -> fma -> exp -> rcp -> ... -> ds_write) then resolve while the
+    // 64-cycle MFMAs of the same wave execute, instead of stalling in front of the barrier.
+    constexpr int NTASK = C::NQT + C::NHT + C::NWT;
+    constexpr int S0 = C::NSTEP / 2;
+    constexpr int TPS = (NTASK + (C::NSTEP - S0) - 1) / (C::NSTEP - S0);  // tasks per step
+    auto store_task = [&](int t, float* nbuf, int ci1) __attribute__((always_inline)) {
+        if (t < C::NQT) {
+            const int j = t;
+            f32x4 q = xq[j];
+            const bool ok = (okbits >> j) & 1;
+            if (PRO != PRO_NONE) {
+                const float2 ad = affs[ci1 + (int)((clbits >> (4 * j)) & 15)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = q[e] * ad.x + ad.y;
+                    if (PRO == PRO_AFFINE_SILU) v = silu_f(v);
+                    q[e] = v;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = ok ? q[e] : 0.f;
+            *reinterpret_cast<f32x4*>(nbuf + qlds[j]) = q;
+        } else if (t < C::NQT + C::NHT) {
+            const bool ok = (okbits >> 8) & 1;
+            float v = xh;
+            if (PRO != PRO_NONE) {
+                const float2 ad = affs[ci1 + (int)(clbits >> 28)];
+                v = v * ad.x + ad.y;
+                if (PRO == PRO_AFFINE_SILU) v = silu_f(v);
+            }
+            nbuf[hlds] = ok ? v : 0.f;
+        } else if (t < NTASK) {
+            const int i = t - C::NQT - C::NHT, e = tid + i * 256;
+            if (C::NW4 % 256 == 0 || e < C::NW4) reinterpret_cast<f32x4*>(nbuf + C::NX)[e] = wv[i];
+        }
+    };
+
     for (int k = 0; k < nchunks; ++k) {
         const float* buf = smem + (k & 1) * C::BUF;
         float* nbuf = smem + ((k + 1) & 1) * C::BUF;
         const bool more = k + 1 < nchunks;
-        if (more) stage_load((k + 1) * CK);
+        const int ci1 = (k + 1) * CK;
+        if (p.prof) ta = __builtin_amdgcn_s_memtime();
+        if (more) stage_load(ci1);
+        if (p.prof) { tb = __builtin_amdgcn_s_memtime(); s_load += tb - ta; }
+        const bool inter = more && ci1 + CK <= p.Cin;  // whole next chunk: branch-free per-step staging
 
         float fa[2][C::MR], fb[2][C::NR];
-        auto frag = [&](int s, float* a, float* bb) {
+        auto frag = [&](int s, float* a, float* bb) __attribute__((always_inline)) {
             const int cp = s / TAPS, t = s % TAPS;
             const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
 #pragma unroll
@@ -255,6 +297,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
             for (int n = 0; n < C::NR; ++n) bb[n] = buf[xoff[n] + cp * 2 * C::XPLANE + dy * C::XS + dx];
         };
         frag(0, fa[0], fb[0]);
+        // (one copy of the unrolled MFMA sequence only: a second copy in an if/else makes hipcc spill the accumulators)
 #pragma unroll
         for (int s = 0; s < C::NSTEP; ++s) {
             if (s + 1 < C::NSTEP) frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
@@ -263,7 +306,12 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
                 for (int n = 0; n < C::NR; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][m], fb[s & 1][n], acc[m][n], 0, 0, 0);
+            if (s >= S0 && inter) {
+#pragma unroll
+                for (int j = 0; j < TPS; ++j) store_task((s - S0) * TPS + j, nbuf, ci1);
+            }
         }
+        if (more && !inter) stage_store(nbuf, ci1);  // partial last chunk (Cin % CK != 0)
         if (ACC2 && ((k + 1) % C::FLUSH == 0)) {
 #pragma unroll
             for (int m = 0; m < C::MR; ++m)
@@ -275,8 +323,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
                         acc[m][n][r] = 0.f;
                     }
         }
-        if (more) stage_store(nbuf, (k + 1) * CK);
+        if (p.prof) { ta = __builtin_amdgcn_s_memtime(); s_mfma += ta - tb; }
         __syncthreads();
+        if (p.prof) { tb = __builtin_amdgcn_s_memtime(); s_bar += tb - ta; }
     }
 
     // ---- epilogue: bias, residual, scale; D layout col = lane&31 (pixel), row = (r&3)+8(r>>2)+4hi ----
@@ -339,11 +388,15 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     }
     if (p.prof && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* o = p.prof + (size_t)blockIdx.x * 4;
+        unsigned long long* o = p.prof + (size_t)blockIdx.x * 8;
         o[0] = t0;
         o[1] = t1;
         o[2] = t2;
         o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = s_load;
+        o[5] = s_mfma;
+        o[6] = s_bar;
+        o[7] = 0;
     }
 }
 

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 B = int(os.environ.get("B", "8"))
 dev = "cuda"
-prof = torch.zeros(1 << 16, 4, dtype=torch.int64, device=dev)
+prof = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
 os.environ["R2DM_CONV_PROF_PTR"] = str(prof.data_ptr())
 from r2dm_amd import _lib
 from bench_conv_shapes import SHAPES
@@ -22,11 +22,8 @@ for n in os.environ.get("SHAPES", "L1_64_64").split(","):
         torch.cuda.synchronize()
     p = prof.cpu()
     p = p[p[:, 3] > 0].double()
-    t0 = p[:, 0].min()
-    clk = 100e6  # s_memtime ticks: constant 100 MHz on gfx9xx? report raw and let the reader scale
-    print(f"{n}: blocks {len(p)}  span(ticks) {(p[:,3].max()-t0):.0f}")
-    for name, a, b_ in (("prologue", 0, 1), ("mainloop", 1, 2), ("epilogue", 2, 3), ("total", 0, 3)):
-        d = p[:, b_] - p[:, a]
-        print(f"   {name:9s} mean {d.mean():9.0f}  min {d.min():9.0f}  max {d.max():9.0f} ticks  ({d.mean()/(p[:,3]-p[:,0]).mean()*100:5.1f}% of block time)")
-    starts = ((p[:, 0] - t0)).sort().values
-    print("   block start ticks (deciles):", [int(starts[int(i*(len(starts)-1)/10)]) for i in range(11)])
+    tot = (p[:, 3] - p[:, 0]).mean()
+    ml = (p[:, 2] - p[:, 1]).mean()
+    print(f"{n}: blocks {len(p)}  block {tot:.0f} cycles = prologue {(p[:,1]-p[:,0]).mean():.0f} + main loop {ml:.0f} + epilogue {(p[:,3]-p[:,2]).mean():.0f}")
+    for name, col in (("issue next chunk's loads", 4), ("mfma + lds reads + interleaved staging", 5), ("barrier", 6)):
+        print(f"   {name:40s} {p[:, col].mean():9.0f} cycles ({p[:, col].mean() / ml * 100:5.1f}% of main loop)")

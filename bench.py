@@ -71,12 +71,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
 
-        td.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI ("nccl" IS RCCL on ROCm); R2DM_DIST_BACKEND=gloo lets two ranks share one GPU in tests
+        backend = os.environ.get("R2DM_DIST_BACKEND", "nccl")
+        td.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     from r2dm_amd.distributed import broadcast_packed_weights, shard_seeds
 
     B = args.batch

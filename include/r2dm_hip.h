@@ -126,9 +126,11 @@ int r2dm_fir_up2(const float* x, float* y, int32_t batch, int32_t channels, int3
  * (models/efficient_unet.py:34-38,46) */
 int r2dm_attention(const float* qkv, float* out, int32_t batch, int32_t channels, int32_t heads, int32_t tokens,
                    void* stream);
-/* time embedding: cond (B,) -> SiLU(time_embedding(cond)) (B,T)  (models/efficient_unet.py:232-237) */
+/* time embedding: cond (B,) -> SiLU(time_embedding(cond)) (B,T)  (models/efficient_unet.py:232-237);
+ * hidden: (B,T) scratch */
 int r2dm_time_embedding(const float* cond, const float* freqs, const float* w1, const float* b1, const float* w2,
-                        const float* b2, float* act, int32_t batch, int32_t base, int32_t temb, void* stream);
+                        const float* b2, float* act, float* hidden, int32_t batch, int32_t base, int32_t temb,
+                        void* stream);
 
 #ifdef __cplusplus
 }

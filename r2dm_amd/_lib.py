@@ -70,7 +70,7 @@ SIGNATURES = {
     "r2dm_fir_down2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "r2dm_fir_up2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "r2dm_attention": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
-    "r2dm_time_embedding": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "r2dm_time_embedding": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -62,6 +62,10 @@ struct ConvParams {
     int taps;            // 9 or 1
     int co_tile;         // 32 / 64 / 128 (must match the packing)
     int prologue;        // Prologue
+    // optional fused GroupNorm statistics of the OUTPUT (for the GroupNorm that consumes it): per (sample, group)
+    // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
+    double* stat = nullptr;
+    int stat_G = 0, stat_goff = 0, stat_cpg = 0, stat_slots = 0;
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
 int conv_pick_co_tile(int Cout, int taps, long pixels_times_batch);
@@ -83,6 +87,9 @@ struct GNParams {
     float* stats;        // optional out [B][G][2] (mean, rstd) for tests, may be nullptr
 };
 int gn_splits(int B, int groups, long group_elems);
+int conv_stat_slots(int H, int W);  // slots per (sample, group) a convolution's fused statistics occupy
+// finalize only: partial [B][G][splits][2] already filled (by a convolution epilogue)
+hipError_t launch_group_norm_finalize(const GNParams& p, int C, int splits, hipStream_t s);
 hipError_t launch_group_norm(const GNParams& p, hipStream_t s);
 hipError_t launch_gn_apply(const float* x, const float2* aff, float* y, int B, int C, long hw, int silu,
                            hipStream_t s);
@@ -104,6 +111,7 @@ struct EmbedParams {
     const float* w2;    // [T][T]
     const float* b2;
     float* act;         // out [B][T] = SiLU(time embedding)
+    float* hidden;      // scratch [B][T]
     int B, base, T;
 };
 hipError_t launch_time_embedding(const EmbedParams& p, hipStream_t s);

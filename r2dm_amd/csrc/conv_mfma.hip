@@ -341,6 +341,12 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     const float* bu = p.bias + co_u;
     // EPI_N pixel segments are processed per pass: all their residual loads are in flight together.
     constexpr int EPI_N = (C::MR * C::NR * 16 <= 64) ? C::NR : (C::NR / 2 > 0 ? C::NR / 2 : 1);
+    double st_s[C::MR][4], st_q[C::MR][4];  // fused GroupNorm statistics (fp64: E[x^2]-E[x]^2 must not see fp32
+                                            // roundoff), per 8-channel block of this wave
+#pragma unroll
+    for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) st_s[m][k8] = st_q[m][k8] = 0.0;
     float bv[C::MR][16];
 #pragma unroll
     for (int m = 0; m < C::MR; ++m)
@@ -383,8 +389,57 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
                     v += bv[m][r];
                     if (ru) v = rv[j][m][r] + v;
                     if (p.scale) v *= sc;
-                    if (px_ok[j] && co_u + cu + 4 * hi < p.Cout) (yu + (long)cu * HW)[loff[j]] = v;
+                    const bool live = px_ok[j] && co_u + cu + 4 * hi < p.Cout;
+                    if (live) (yu + (long)cu * HW)[loff[j]] = v;
+                    if (p.stat) {
+                        const double vm = live ? (double)v : 0.0;
+                        st_s[m][r >> 2] += vm;
+                        st_q[m][r >> 2] = fma(vm, vm, st_q[m][r >> 2]);
+                    }
                 }
+    }
+    if (p.stat) {
+        // lanes of a wave hold 4 of the 8 channels (by half-wave) x 32 pixels of every 8-channel block: reduce over
+        // the wave in fp64, merge the blocks of a group, one slot per (pixel tile, pixel wave) -- fixed order.
+        double bs[C::MR * 4], bq[C::MR * 4];
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) {
+                double a = st_s[m][k8], q = st_q[m][k8];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                bs[m * 4 + k8] = a;
+                bq[m * 4 + k8] = q;
+            }
+        if (lane == 0) {
+            const int bpg = p.stat_cpg >> 3;                 // 8-channel blocks per group
+            const int slot = (th * nTw + tw) * 4 + wave_px;  // 4 slots per pixel tile (unused ones hold zeros)
+#pragma unroll
+            for (int g0 = 0; g0 < C::MR * 4; ++g0) {
+                if (g0 % bpg) continue;
+                double a = 0.0, q = 0.0;
+#pragma unroll
+                for (int k8 = 0; k8 < C::MR * 4; ++k8)
+                    if (k8 >= g0 && k8 < g0 + bpg) {
+                        a += bs[k8];
+                        q += bq[k8];
+                    }
+                const int g = p.stat_goff + (co_u + g0 * 8) / p.stat_cpg;
+                if (co_u + g0 * 8 < p.Cout) {
+                    double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2;
+                    o[0] = a;
+                    o[1] = q;
+                    if (WPX == 2) {  // this variant fills only 2 of the tile's 4 slots
+                        o[4] = 0.0;
+                        o[5] = 0.0;
+                    }
+                }
+            }
+        }
     }
     if (p.prof && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -442,6 +497,8 @@ int conv_pick_co_tile(int Cout, int taps, long px_batch) {
     }
     return 64;
 }
+
+int conv_stat_slots(int H, int W) { return ((H + 3) / 4) * ((W + 63) / 64) * 4; }
 
 int conv_cin_pad(int Cin, int taps, int co_tile) {
     const int ck = taps == 9 ? (co_tile == 128 ? kCK3_128 : co_tile == 64 ? kCK3_64_DEEP : kCK3_32) : kCK1;

@@ -24,12 +24,13 @@ __device__ __forceinline__ float silu_exact(float v) {
     return (float)(d / (1.0 + exp(-d)));
 }
 
-// grid = B, block = 256.  One wave per output row, lanes stride the reduction dimension.
-__global__ __launch_bounds__(256) void time_embedding_kernel(EmbedParams p) {
-    extern __shared__ float sm[];  // [base] sinusoid, then [T] hidden
-    float* emb = sm;
-    float* hid = sm + p.base;
-    const int b = blockIdx.x, half = p.base / 2;
+// Two launches so that the 64 KB + 256 KB weight matrices are streamed by many CUs instead of one block per
+// sample (one block per sample took 160 us -- 1 % of a sampling step -- for a few hundred KFLOP):
+//   hidden: grid (T/4, B): emb = [sin, cos](t * f_k) recomputed per block (cheap), wave w -> row 4*bx + w of W1
+//   output: grid (T/4, B): wave w -> row 4*bx + w of W2
+__global__ __launch_bounds__(256) void time_hidden_kernel(EmbedParams p, float* __restrict__ hid) {
+    extern __shared__ float emb[];  // [base]
+    const int b = blockIdx.y, half = p.base / 2;
     const float t = p.cond[b];
     for (int k = threadIdx.x; k < half; k += 256) {
         const float arg = t * p.freqs[k];  // fp32 product, as the reference forms it (ops.py:24)
@@ -37,24 +38,29 @@ __global__ __launch_bounds__(256) void time_embedding_kernel(EmbedParams p) {
         emb[half + k] = (float)cos((double)arg);
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = wave; r < p.T; r += 4) {
-        double acc = 0.0;
-        for (int k = lane; k < p.base; k += 64) acc += (double)p.w1[(long)r * p.base + k] * (double)emb[k];
-        acc = wave_sum_d(acc);
-        if (lane == 0) hid[r] = silu_exact((float)(acc + (double)p.b1[r]));
-    }
-    __syncthreads();
-    for (int r = wave; r < p.T; r += 4) {
-        double acc = 0.0;
-        for (int k = lane; k < p.T; k += 64) acc += (double)p.w2[(long)r * p.T + k] * (double)hid[k];
-        acc = wave_sum_d(acc);
-        if (lane == 0) p.act[(long)b * p.T + r] = silu_exact((float)(acc + (double)p.b2[r]));
-    }
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= p.T) return;
+    double acc = 0.0;
+    for (int k = lane; k < p.base; k += 64) acc += (double)p.w1[(long)r * p.base + k] * (double)emb[k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) hid[(long)b * p.T + r] = silu_exact((float)(acc + (double)p.b1[r]));
+}
+
+__global__ __launch_bounds__(256) void time_out_kernel(EmbedParams p, const float* __restrict__ hid) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= p.T) return;
+    double acc = 0.0;
+    for (int k = lane; k < p.T; k += 64) acc += (double)p.w2[(long)r * p.T + k] * (double)hid[(long)b * p.T + k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) p.act[(long)b * p.T + r] = silu_exact((float)(acc + (double)p.b2[r]));
 }
 
 hipError_t launch_time_embedding(const EmbedParams& p, hipStream_t s) {
-    time_embedding_kernel<<<p.B, 256, (p.base + p.T) * sizeof(float), s>>>(p);
+    if (!p.hidden) return hipErrorInvalidValue;
+    const dim3 g((p.T + 3) / 4, p.B);
+    time_hidden_kernel<<<g, 256, p.base * sizeof(float), s>>>(p, p.hidden);
+    time_out_kernel<<<g, 256, 0, s>>>(p, p.hidden);
     return hipGetLastError();
 }
 

@@ -297,6 +297,42 @@ struct Ctx {
     }
     void drop(const Tensor& t) { ar->release(t.p); }
 
+    // Fused statistics: a convolution whose output feeds a GroupNorm leaves per-(sample, group) partial sums in a
+    // Sink from its epilogue; the GroupNorm then only runs the finalize kernel (no extra pass over the tensor).
+    struct Sink {
+        double* p = nullptr;
+        int C = 0, cpg = 0, slots = 0;  // C: channels of the normalised (possibly concatenated) tensor
+        explicit operator bool() const { return p != nullptr; }
+    };
+    Sink make_sink(int C_total, int H, int W) {
+        Sink k;
+        const int G = h->cfg.gn_num_groups;
+        const int cpg = C_total / G;
+        if (C_total % G || cpg % 8 || cpg > 64) return k;  // shapes the epilogue reduction does not cover: separate pass
+        k.C = C_total;
+        k.cpg = cpg;
+        k.slots = conv_stat_slots(H, W);
+        k.p = (double*)ar->alloc((size_t)B * G * k.slots * 2 * sizeof(double));
+        return k;
+    }
+    void drop_sink(Sink& k) {
+        if (k.p) ar->release(k.p);
+        k.p = nullptr;
+    }
+    float2* finalize(const Sink& k, int H, int W, const float* gamma, const float* beta, const float* ada) {
+        float2* aff = (float2*)ar->alloc((size_t)B * k.C * sizeof(float2));
+        if (!dry()) {
+            GNParams g{Src{}, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows, k.p, aff,
+                       nullptr};
+            note(launch_group_norm_finalize(g, k.C, k.slots, st), "group_norm_finalize");
+        }
+        return aff;
+    }
+    // GroupNorm of `x`: from fused statistics when the producer left them, else with the streaming statistics pass
+    float2* norm(const Sink& k, const Src& x, int H, int W, const float* gamma, const float* beta, const float* ada) {
+        return k ? finalize(k, H, W, gamma, beta, ada) : group_norm(x, H, W, gamma, beta, ada);
+    }
+
     float2* group_norm(const Src& x, int H, int W, const float* gamma, const float* beta, const float* ada) {
         const int C = x.c0 + x.c1;
         float2* aff = (float2*)ar->alloc((size_t)B * C * sizeof(float2));
@@ -309,7 +345,7 @@ struct Ctx {
     }
 
     Tensor conv(const ConvLayer& L, const Src& x, int H, int W, int pro, const float2* aff, const Tensor* res,
-                size_t scale_off, bool has_scale, float* dst = nullptr) {
+                size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0) {
         Tensor y;
         y.C = L.cout;
         y.H = H;
@@ -335,6 +371,13 @@ struct Ctx {
             p.taps = L.taps;
             p.co_tile = L.co_tile;
             p.prologue = pro;
+            if (sink && *sink && L.co_tile >= 64) {
+                p.stat = sink->p;
+                p.stat_G = h->cfg.gn_num_groups;
+                p.stat_goff = goff;
+                p.stat_cpg = sink->cpg;
+                p.stat_slots = sink->slots;
+            }
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof_on) {
                 if (h->prof_used + 2 > h->prof_ev.size()) {
@@ -358,12 +401,15 @@ struct Ctx {
         return y;
     }
 
-    // efficient_unet.py:95-110
-    Tensor residual_block(const ResLayer& r, const Src& x, int H, int W) {
-        float2* a1 = group_norm(x, H, W, blob(r.g1), blob(r.b1), nullptr);
-        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, a1, nullptr, 0, false);
+    // efficient_unet.py:95-110.  `in_stats`: fused statistics of x (if its producer left them);
+    // `out` / `out_goff`: where the statistics of this block's output go (the next GroupNorm's sink).
+    Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff) {
+        float2* a1 = norm(in_stats, x, H, W, blob(r.g1), blob(r.b1), nullptr);
+        Sink s1 = make_sink(r.cout, H, W);
+        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, a1, nullptr, 0, false, nullptr, &s1, 0);
         ar->release(a1);
-        float2* a2 = group_norm(src1(t1), H, W, nullptr, nullptr, proj + r.ada_row);
+        float2* a2 = norm(s1, src1(t1), H, W, nullptr, nullptr, proj + r.ada_row);
+        drop_sink(s1);
         Tensor skip;
         const Tensor* res;
         Tensor ident;
@@ -377,30 +423,34 @@ struct Ctx {
             ident.W = W;
             res = &ident;
         }
-        Tensor out = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, a2, res, r.scale, true);
+        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, a2, res, r.scale, true, nullptr, out, out_goff);
         ar->release(a2);
         drop(t1);
         if (r.has_skip) drop(skip);
-        return out;
+        return o;
     }
 
     // efficient_unet.py:42-53
-    Tensor attention_block(const AttnLayer& a, const Tensor& x) {
-        float2* aff = group_norm(src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
+    Tensor attention_block(const AttnLayer& a, const Tensor& x, const Sink& in_stats, const Sink* out, int out_goff) {
+        float2* aff = norm(in_stats, src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
         Tensor qkv = conv(a.qkv, src1(x), x.H, x.W, PRO_AFFINE, aff, nullptr, 0, false);
         ar->release(aff);
         Tensor o = make(a.C, x.H, x.W);
         if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st), "attention");
         drop(qkv);
-        Tensor out = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true);
+        Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff);
         drop(o);
-        return out;
+        return y;
     }
 
-    // efficient_unet.py:178-185.  Never frees `in`; returns a fresh tensor.
-    Tensor stage(const Stage& s, const Src& in, int H, int W) {
+    // efficient_unet.py:178-185.  Never frees `in`; returns a fresh tensor.  `in_stats`: fused statistics of `in` for
+    // the first residual block (stages without downsampling); `out`/`out_goff`: sink of the GroupNorm that will consume
+    // this stage's output (written by whichever convolution produces it last).
+    Tensor stage(const Stage& s, const Src& in, int H, int W, const Sink& in_stats, const Sink* out, int out_goff) {
         Tensor cur;
         bool have = false;
+        Sink carry = in_stats;  // statistics of the current tensor, owned elsewhere for the stage input
+        bool carry_owned = false;
         if (s.down) {
             Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false);
             cur = make(s.cout, H / 2, W / 2);
@@ -409,23 +459,42 @@ struct Ctx {
             H /= 2;
             W /= 2;
             have = true;
+            carry = Sink{};  // the FIR output has no fused statistics: streaming pass
         }
-        for (const ResLayer& r : s.res) {
-            Tensor nxt = residual_block(r, have ? src1(cur) : in, H, W);
+        const int n = (int)s.res.size();
+        for (int i = 0; i < n; ++i) {
+            const bool last = i == n - 1;
+            Sink next;  // sink for the GroupNorm that consumes this block's output inside the stage
+            const Sink* dst = nullptr;
+            int goff = 0;
+            if (!last || s.attn) {
+                next = make_sink(s.cout, H, W);
+                dst = &next;
+            } else if (!s.up) {
+                dst = out;
+                goff = out_goff;
+            }
+            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff);
+            if (carry_owned) drop_sink(carry);
             if (have) drop(cur);
             cur = nxt;
             have = true;
+            carry = next;
+            carry_owned = (bool)next;
         }
         if (s.attn) {
-            Tensor nxt = attention_block(s.at, cur);
+            Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff);
+            if (carry_owned) drop_sink(carry);
+            carry_owned = false;
             drop(cur);
             cur = nxt;
         }
+        if (carry_owned) drop_sink(carry);
         if (s.up) {
             Tensor u = make(s.cout, 2 * H, 2 * W);
             if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st), "fir_up2");
             drop(cur);
-            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false);
+            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff);
             drop(u);
         }
         return cur;
@@ -436,36 +505,51 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     const r2dm_config& c = h->cfg;
     Ctx k{h, &ar, st, B, nullptr, nullptr};
     const int H = c.height, W = c.width, T = c.temb_channels;
-    float* act = (float*)ar.alloc((size_t)B * T * sizeof(float));
+    float* act = (float*)ar.alloc((size_t)2 * B * T * sizeof(float));  // [SiLU(temb) | hidden scratch]
     float* proj = (float*)ar.alloc((size_t)B * h->ada_rows * sizeof(float));
     k.gn_partial = (double*)ar.alloc((size_t)B * c.gn_num_groups * 256 * 2 * sizeof(double));
     k.proj = proj;
     if (!k.dry()) {
-        EmbedParams e{cond, k.blob(h->freqs), k.blob(h->w1), k.blob(h->b1), k.blob(h->w2), k.blob(h->b2), act, B,
-                      c.base_channels, T};
+        EmbedParams e{cond, k.blob(h->freqs), k.blob(h->w1), k.blob(h->b1), k.blob(h->w2), k.blob(h->b2), act,
+                      act + (size_t)B * T, B, c.base_channels, T};
         k.note(launch_time_embedding(e, st), "time_embedding");
         k.note(launch_ada_proj(act, k.blob(h->ada_w), k.blob(h->ada_b), proj, B, T, h->ada_rows, st), "ada_proj");
     }
     // input = cat([x, cenc]) without materialising it (efficient_unet.py:278-281)
     Src in{x, c.coord_channels ? k.blob(h->cenc) : nullptr, c.in_channels, c.coord_channels,
            (long)c.in_channels * H * W, 0};
-    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false);
-    Tensor h1 = k.stage(h->stages[0], src1(h0), H, W);
+    const int G = c.gn_num_groups;
+    const Stage* S = h->stages;
+    // GroupNorm sinks that outlive a stage: the first norm of d_block1 (input = in_conv output) and the first norm of
+    // every up stage (input = cat([up-path tensor, skip tensor]): groups [0, G/2) come from the up path, [G/2, G)
+    // from the skip tensor produced much earlier on the down path).
+    Ctx::Sink s_d1 = k.make_sink(S[0].cin, H, W);
+    Ctx::Sink s_u1 = k.make_sink(S[7].cin, H, W);
+    Ctx::Sink s_u2 = k.make_sink(S[6].cin, H / 2, W / 2);
+    Ctx::Sink s_u3 = k.make_sink(S[5].cin, H / 4, W / 4);
+    Ctx::Sink s_u4 = k.make_sink(S[4].cin, H / 8, W / 8);
+    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, &s_d1, 0);
+    Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2);
     k.drop(h0);
-    Tensor h2 = k.stage(h->stages[1], src1(h1), H, W);
-    Tensor h3 = k.stage(h->stages[2], src1(h2), H / 2, W / 2);
-    Tensor h4 = k.stage(h->stages[3], src1(h3), H / 4, W / 4);
-    Tensor u = k.stage(h->stages[4], src1(h4), H / 8, W / 8);
+    k.drop_sink(s_d1);
+    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2);
+    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2);
+    Tensor h4 = k.stage(S[3], src1(h3), H / 4, W / 4, Ctx::Sink{}, &s_u4, 0);
+    Tensor u = k.stage(S[4], src1(h4), H / 8, W / 8, s_u4, &s_u3, 0);
     k.drop(h4);
-    Tensor u3 = k.stage(h->stages[5], src2(u, h3), H / 4, W / 4);
+    k.drop_sink(s_u4);
+    Tensor u3 = k.stage(S[5], src2(u, h3), H / 4, W / 4, s_u3, &s_u2, 0);
     k.drop(u);
     k.drop(h3);
-    Tensor u2 = k.stage(h->stages[6], src2(u3, h2), H / 2, W / 2);
+    k.drop_sink(s_u3);
+    Tensor u2 = k.stage(S[6], src2(u3, h2), H / 2, W / 2, s_u2, &s_u1, 0);
     k.drop(u3);
     k.drop(h2);
-    Tensor u1 = k.stage(h->stages[7], src2(u2, h1), H, W);
+    k.drop_sink(s_u2);
+    Tensor u1 = k.stage(S[7], src2(u2, h1), H, W, s_u1, nullptr, 0);
     k.drop(u2);
     k.drop(h1);
+    k.drop_sink(s_u1);
     k.conv(h->out_conv, src1(u1), H, W, PRO_NONE, nullptr, nullptr, 0, false, out);
     k.drop(u1);
     ar.release(act);
@@ -694,8 +778,9 @@ int r2dm_attention(const float* qkv, float* out, int32_t B, int32_t C, int32_t h
 }
 
 int r2dm_time_embedding(const float* cond, const float* freqs, const float* w1, const float* b1, const float* w2,
-                        const float* b2, float* act, int32_t B, int32_t base, int32_t T, void* stream) {
-    EmbedParams e{cond, freqs, w1, b1, w2, b2, act, B, base, T};
+                        const float* b2, float* act, float* hidden, int32_t B, int32_t base, int32_t T, void* stream) {
+    if (!cond || !freqs || !w1 || !b1 || !w2 || !b2 || !act || !hidden) return fail(1, "null argument");
+    EmbedParams e{cond, freqs, w1, b1, w2, b2, act, hidden, B, base, T};
     HIP_TRY(launch_time_embedding(e, (hipStream_t)stream));
     return 0;
 }

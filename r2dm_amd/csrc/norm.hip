@@ -83,10 +83,12 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
     const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x;
     const double* p = partial + ((long)b * G + g) * splits * 2;
     double sum = 0.0, sq = 0.0;
-    for (int s = 0; s < splits; ++s) {
+    for (int s = threadIdx.x; s < splits; s += 64) {  // fixed lane -> slot assignment: deterministic
         sum += p[2 * s];
         sq += p[2 * s + 1];
     }
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
     const double n = (double)cpg * (double)hw;
     const double mean_d = sum / n;
     double var_d = sq / n - mean_d * mean_d;
@@ -132,6 +134,13 @@ hipError_t launch_group_norm(const GNParams& p, hipStream_t st) {
     gn_partial_kernel<<<dim3(splits, p.groups, p.B), kGnThreads, 0, st>>>(p.x, cpg, hw, splits, p.partial);
     gn_finalize_kernel<<<dim3(p.groups, p.B), 64, 0, st>>>(p.partial, splits, C, cpg, hw, p.eps, p.gamma, p.beta,
                                                             p.ada, p.ada_stride, p.aff, p.stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_norm_finalize(const GNParams& p, int C, int splits, hipStream_t st) {
+    if (C % p.groups) return hipErrorInvalidValue;
+    gn_finalize_kernel<<<dim3(p.groups, p.B), 64, 0, st>>>(p.partial, splits, C, C / p.groups, (long)p.H * p.W, p.eps, p.gamma,
+                                                            p.beta, p.ada, p.ada_stride, p.aff, p.stats);
     return hipGetLastError();
 }
 

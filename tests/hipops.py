@@ -72,7 +72,9 @@ def attention(qkv, heads):
 def time_embedding(cond, freqs, w1, b1, w2, b2):
     B, T, base = cond.shape[0], w1.shape[0], w1.shape[1]
     act = torch.empty(B, T, device=cond.device)
+    hid = torch.empty(B, T, device=cond.device)
     _lib.check(_lib.lib().r2dm_time_embedding(cond.data_ptr(), freqs.data_ptr(), w1.data_ptr(), b1.data_ptr(),
-                                             w2.data_ptr(), b2.data_ptr(), act.data_ptr(), B, base, T, _st(cond)))
+                                             w2.data_ptr(), b2.data_ptr(), act.data_ptr(), hid.data_ptr(), B, base, T,
+                                             _st(cond)))
     torch.cuda.synchronize()
     return act

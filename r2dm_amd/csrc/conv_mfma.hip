@@ -287,20 +287,38 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
         if (p.prof) { tb = __builtin_amdgcn_s_memtime(); s_load += tb - ta; }
         const bool inter = more && ci1 + CK <= p.Cin;  // whole next chunk: branch-free per-step staging
 
+        // MFMA operand fragments are read from LDS ONE K-step ahead of their use.  hipcc sinks every ds_read next to
+        // its consumer (exposing the LDS latency in front of each group of MFMAs: ~8 % of the loop), so the reads are
+        // issued by hand (inline asm, immediate offsets) and retired with a counted lgkmcnt: LDS operations complete
+        // in order, so "at most MR+NR outstanding" means the previous step's fragments have landed whatever other
+        // LDS traffic (staging writes, table reads) the compiler placed in between.
         float fa[2][C::MR], fb[2][C::NR];
+        const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)buf + 4u * (unsigned)woff;
+        unsigned lds_x[C::NR];
+#pragma unroll
+        for (int n = 0; n < C::NR; ++n)
+            lds_x[n] = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)buf + 4u * (unsigned)xoff[n];
         auto frag = [&](int s, float* a, float* bb) __attribute__((always_inline)) {
             const int cp = s / TAPS, t = s % TAPS;
             const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
 #pragma unroll
-            for (int m = 0; m < C::MR; ++m) a[m] = buf[woff + (cp * 2 * TAPS + t) * CO_T + m * 32];
+            for (int m = 0; m < C::MR; ++m)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[m]) : "v"(lds_w), "i"(4 * ((cp * 2 * TAPS + t) * CO_T + m * 32)));
 #pragma unroll
-            for (int n = 0; n < C::NR; ++n) bb[n] = buf[xoff[n] + cp * 2 * C::XPLANE + dy * C::XS + dx];
+            for (int n = 0; n < C::NR; ++n)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bb[n]) : "v"(lds_x[n]), "i"(4 * (cp * 2 * C::XPLANE + dy * C::XS + dx)));
         };
         frag(0, fa[0], fb[0]);
         // (one copy of the unrolled MFMA sequence only: a second copy in an if/else makes hipcc spill the accumulators)
 #pragma unroll
         for (int s = 0; s < C::NSTEP; ++s) {
-            if (s + 1 < C::NSTEP) frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            if (s + 1 < C::NSTEP) {
+                frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(C::MR + C::NR) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (they do not touch memory)
 #pragma unroll
             for (int m = 0; m < C::MR; ++m)
 #pragma unroll

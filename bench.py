@@ -55,6 +55,16 @@ def cpu_baseline(ck):
                       f"of {os.cpu_count()} host cores, {dt / n:.3f} s/step, scaled to the 256-step sampler"}
 
 
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed PMC passes (scripts/summarize_profile.py); PMC counters cannot be
+    collected from inside the timed process, so this is the figure of the last profiled run of this same command."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv_traffic.json")) as f:
+            return float(json.load(f)["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,12 +151,14 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
                        "sampler_steps": SAMPLER_STEPS, "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
             "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_FP32 / 1e12, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] * 1e12 / PEAK_FP32, "traffic": None,
+                         "frac": conv["tflops"] * 1e12 / PEAK_FP32, "traffic": pmc_traffic(),
                          "dominant_kernel": conv,
                          "whole_step": {"achieved": step_flops / 1e12, "frac": step_flops / PEAK_FP32,
                                         "note": "234.52 GFLOP/image-step x batch / HIP-event time of the timed sample() call"},
                          "note": "achieved = sum of algorithmic conv FLOPs / sum of conv kernel time (HIP events on the sampling "
-                                 "stream, rank 0); peak = MI355X fp32 MFMA = fp32 vector peak; traffic: see profiles/ (PMC pass)"},
+                                 "stream, rank 0); peak = MI355X fp32 MFMA = fp32 vector peak; traffic = HBM bytes per conv launch "
+                                 "from the last committed rocprofv3 PMC passes (profiles/conv_traffic.json: 2 x FETCH_SIZE + "
+                                 "WRITE_SIZE), null if that file is absent; algorithmic bytes per launch = 147.7 MB"},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ck)

@@ -6,8 +6,8 @@ OUT=../libr2dm_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
-for f in conv_mfma norm resample attention embed posterior engine; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/r2dm_hip.h -nt build/$f.o ]; then
+for f in conv_mfma conv_bf16x3 norm resample attention embed posterior engine; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || [ ../../include/r2dm_hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

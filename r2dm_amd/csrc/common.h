@@ -47,6 +47,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // ---- kernel launchers (each in its own .hip) ------------------------------------------
 
 enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2 };
+// ALGO_F32: fp32-input MFMA (conv_mfma.hip).  ALGO_BF16X3: fp32 operands split exactly into three bf16 pieces, six
+// bf16 MFMA products per fp32 product, fp32 accumulation (conv_bf16x3.hip) -- same accuracy class, 2.7x fewer
+// matrix-pipe cycles; needs 3x3, Cin % 16 == 0, Cout % 64 == 0.
+enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1 };
 
 struct ConvParams {
     Src x;               // input activation
@@ -62,17 +66,24 @@ struct ConvParams {
     int taps;            // 9 or 1
     int co_tile;         // 32 / 64 / 128 (must match the packing)
     int prologue;        // Prologue
+    int algo = ALGO_F32; // ConvAlgo (must match the packing of `w`)
     // optional fused GroupNorm statistics of the OUTPUT (for the GroupNorm that consumes it): per (sample, group)
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
     double* stat = nullptr;
     int stat_G = 0, stat_goff = 0, stat_cpg = 0, stat_slots = 0;
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
+int conv_pick_algo(int Cin, int Cout, int taps);  // env R2DM_CONV_ALGO=f32 forces ALGO_F32 everywhere
+long conv_packed_floats(int algo, int Cin, int Cout, int taps, int co_tile, int cin_pad);
 int conv_pick_co_tile(int Cout, int taps, long pixels_times_batch);
 int conv_cin_pad(int Cin, int taps, int co_tile);
 hipError_t launch_conv(const ConvParams& p, hipStream_t s);
 hipError_t launch_pack_conv(const float* w_oihw, float* dst, int Cout, int Cin, int taps, int co_tile,
-                            int cin_pad, hipStream_t s);
+                            int cin_pad, hipStream_t s, int algo = ALGO_F32);
+bool conv_bf16x3_supported(int Cin, int Cout, int taps);
+long conv_bf16x3_packed_floats(int Cin, int Cout);
+hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, hipStream_t s);
+hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s);
 
 struct GNParams {
     Src x;

@@ -23,6 +23,7 @@
 // Accuracy: with ACC2 the accumulators are flushed into a second register set every 64 input
 // channels (576 products), so roundoff grows with sqrt(576) not sqrt(K) (K up to 4608).
 #include "common.h"
+#include <stdlib.h>
 
 namespace r2dm {
 
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
         o[4] = s_load;
         o[5] = s_mfma;
         o[6] = s_bar;
-        o[7] = 0;
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
     }
 }
 
@@ -489,7 +490,8 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int co_tile, int cin_pad,
-                            hipStream_t s) {
+                            hipStream_t s, int algo) {
+    if (algo == ALGO_BF16X3) return launch_pack_conv_bf16x3(w, dst, Cout, Cin, s);
     const int nT = (Cout + co_tile - 1) / co_tile;
     const long total = (long)nT * cin_pad * taps * co_tile;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -505,6 +507,19 @@ hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int t
 //   3x3  "D32" (out_conv)    32   1 x 4           8    32              3
 //   1x1                   32/64/128               16
 constexpr int kCK3_128 = 4, kCK3_64 = 4, kCK3_64_DEEP = 8, kCK3_32 = 8, kCK1 = 16;
+
+int conv_pick_algo(int Cin, int Cout, int taps) {
+    static const bool force_f32 = [] {
+        const char* e = getenv("R2DM_CONV_ALGO");
+        return e && e[0] == 'f';
+    }();
+    return !force_f32 && conv_bf16x3_supported(Cin, Cout, taps) ? ALGO_BF16X3 : ALGO_F32;
+}
+
+long conv_packed_floats(int algo, int Cin, int Cout, int taps, int co_tile, int cin_pad) {
+    if (algo == ALGO_BF16X3) return conv_bf16x3_packed_floats(Cin, Cout);
+    return (long)((Cout + co_tile - 1) / co_tile) * cin_pad * taps * co_tile;
+}
 
 int conv_pick_co_tile(int Cout, int taps, long px_batch) {
     (void)taps;
@@ -552,6 +567,7 @@ static hipError_t launch_pro(const ConvParams& p, hipStream_t s) {
 }
 
 hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
+    if (p.algo == ALGO_BF16X3) return launch_conv_bf16x3(p, s);
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.CinPad != conv_cin_pad(p.Cin, p.taps, p.co_tile)) return hipErrorInvalidValue;
     if (p.H * (long)p.W * 16 >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit element offsets within a chunk

@@ -43,9 +43,9 @@ inline size_t align_up(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a
 
 // ---- plan -----------------------------------------------------------------------------------
 struct ConvLayer {
-    int cin = 0, cout = 0, taps = 0, co_tile = 0, cin_pad = 0;
+    int cin = 0, cout = 0, taps = 0, co_tile = 0, cin_pad = 0, algo = 0;
     size_t w = 0, b = 0;  // blob offsets in floats
-    size_t packed_elems() const { return (size_t)((cout + co_tile - 1) / co_tile) * cin_pad * taps * co_tile; }
+    size_t packed_elems() const { return (size_t)conv_packed_floats(algo, cin, cout, taps, co_tile, cin_pad); }
 };
 
 struct ResLayer {
@@ -115,8 +115,9 @@ struct r2dm_handle {
         L.cin = cin;
         L.cout = cout;
         L.taps = ksize * ksize;
-        L.co_tile = conv_pick_co_tile(cout, L.taps, px_batch);
-        L.cin_pad = conv_cin_pad(cin, L.taps, L.co_tile);
+        L.algo = conv_pick_algo(cin, cout, L.taps);
+        L.co_tile = L.algo == ALGO_BF16X3 ? 64 : conv_pick_co_tile(cout, L.taps, px_batch);
+        L.cin_pad = L.algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
         L.w = take(L.packed_elems());
         slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
         L.b = raw(bkey, cout);
@@ -370,6 +371,7 @@ struct Ctx {
             p.Cout = L.cout;
             p.taps = L.taps;
             p.co_tile = L.co_tile;
+            p.algo = L.algo;
             p.prologue = pro;
             if (sink && *sink && L.co_tile >= 64) {
                 p.stat = sink->p;
@@ -636,7 +638,7 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
         HIP_TRY(hipMemcpyAsync(h->blob + s.off, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         HIP_TRY(launch_pack_conv(src, h->blob + s.off, s.conv.cout, s.conv.cin, s.conv.taps, s.conv.co_tile,
-                                 s.conv.cin_pad, st));
+                                 s.conv.cin_pad, st, s.conv.algo));
     }
     return 0;
 }
@@ -707,8 +709,9 @@ int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_
 // ---- single-kernel entry points (unit parity tests) ---------------------------------------------
 int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t B, int32_t H, int32_t W) {
     const int taps = ksize * ksize;
-    const int ct = conv_pick_co_tile(cout, taps, (long)B * H * W);
-    return (int64_t)((cout + ct - 1) / ct) * conv_cin_pad(cin, taps, ct) * taps * ct;
+    const int algo = conv_pick_algo(cin, cout, taps);
+    const int ct = algo == ALGO_BF16X3 ? 64 : conv_pick_co_tile(cout, taps, (long)B * H * W);
+    return (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, taps, ct));
 }
 
 int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w_packed, const float* aff,
@@ -719,9 +722,10 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     hipStream_t st = (hipStream_t)stream;
     ConvParams p;
     p.taps = ksize * ksize;
-    p.co_tile = conv_pick_co_tile(cout, p.taps, (long)B * H * W);
-    p.CinPad = conv_cin_pad(cin, p.taps, p.co_tile);
-    HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st));
+    p.algo = conv_pick_algo(cin, cout, p.taps);
+    p.co_tile = p.algo == ALGO_BF16X3 ? 64 : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    p.CinPad = p.algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
+    HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
     p.x = Src{x, nullptr, cin, 0, (long)cin * H * W, 0};
     p.w = w_packed;
     p.bias = bias;

@@ -67,6 +67,7 @@ struct ConvParams {
     int co_tile;         // 32 / 64 / 128 (must match the packing)
     int prologue;        // Prologue
     int algo = ALGO_F32; // ConvAlgo (must match the packing of `w`)
+    int sign_shift = 0;  // ALGO_BF16X3 shallow kernel: accumulator sign flips every 2^sign_shift chunks (set by the launcher)
     // optional fused GroupNorm statistics of the OUTPUT (for the GroupNorm that consumes it): per (sample, group)
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
     double* stat = nullptr;

@@ -19,6 +19,8 @@
 // transforms its next chunk (GroupNorm affine, SiLU, split, pack: VALU) the other one owns the matrix pipe.
 #include "common.h"
 #include "conv_epilogue.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace r2dm {
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, ACC2 ? 1 : 2) void conv_bf16x3_kernel(const Co
     L /= nTw;
     const int th = L % nTh;
     const int b = L / nTh;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;  // perf probe (scripts/conv_phases.py)
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, ta = 0, tb = 0, s_load = 0, s_mfma = 0, s_bar = 0, s_xf = 0;  // perf probe
     if (p.prof) t0 = __builtin_amdgcn_s_memtime();
 
     // ---- x staging unit of this thread (constant over the block) ----
@@ -204,12 +206,14 @@ __global__ __launch_bounds__(256, ACC2 ? 1 : 2) void conv_bf16x3_kernel(const Co
 
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
+        if (p.prof) ta = __builtin_amdgcn_s_memtime();
         if (more) load_x((c + 1) * CK);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int sigma = c * 3 + ky;
             const bool last = !more && ky == 2;
             if (!last) load_w(sigma + 1);
+            if (p.prof) { tb = __builtin_amdgcn_s_memtime(); s_load += tb - ta; }
             const unsigned lds_w = lds_w0 + (unsigned)((sigma & 1) * WBYTES);
             // operand fragments are fetched one tap ahead of their use with hand-issued ds_read_b128 and retired with
             // a counted lgkmcnt (LDS operations complete in order; see conv_mfma.hip)
@@ -252,23 +256,28 @@ __global__ __launch_bounds__(256, ACC2 ? 1 : 2) void conv_bf16x3_kernel(const Co
                                 __builtin_bit_cast(bf16x8, fb[tx & 1][PJ[q]][n]), acc[m][n], 0, 0, 0);
             }
             if (!last) store_w((sigma + 1) & 1);
+            if (p.prof) { ta = __builtin_amdgcn_s_memtime(); s_mfma += ta - tb; }
             __syncthreads();
+            if (p.prof) { tb = __builtin_amdgcn_s_memtime(); s_bar += tb - ta; ta = tb; }
         }
         if (more) {
             store_x();  // every wave is past its last read of this chunk's tile
             __syncthreads();
         }
+        if (p.prof) { tb = __builtin_amdgcn_s_memtime(); s_xf += tb - ta; }
         // v_mfma_f32_32x32x16_bf16 rounds its accumulation toward -inf-ish (measured: the error of +A*B and of -A*B
         // are BOTH negative, ~-7e-11 per instruction at O(1) sums -- a coherent offset that a 256-step sampler
         // amplifies, unlike the zero-mean rounding of the fp32 FMA).  The accumulator therefore changes sign after
-        // every chunk and odd chunks use pre-negated weights: acc = (-1)^c * S_c, so consecutive chunks push the
-        // offset in opposite directions and it cancels (Cin/16 is even).
+        // every second chunk and chunk pairs 1, 3, ... use pre-negated weights: acc = (-1)^(c/2) * S_c, so consecutive
+        // pairs push the offset in opposite directions and it cancels (Cin/32 is even).
+        if (((c + 1) & ((1 << p.sign_shift) - 1)) == 0) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+            for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int n = 0; n < NR; ++n)
+                for (int n = 0; n < NR; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = -acc[m][n][r];
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = -acc[m][n][r];
+        }
         if (ACC2 && ((c + 1) % 4 == 0)) {  // two-level accumulation: flush every 64 input channels
 #pragma unroll
             for (int m = 0; m < MR; ++m)
@@ -292,6 +301,419 @@ __global__ __launch_bounds__(256, ACC2 ? 1 : 2) void conv_bf16x3_kernel(const Co
         o[1] = t1;
         o[2] = t2;
         o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = s_load;
+        o[5] = s_mfma;
+        o[6] = s_bar + (s_xf << 32);
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+}
+
+// ---- deep variant: one software-pipelined instruction stream per wave, one block per CU ------------------------
+// For long reductions (Cin > 128) the two-level accumulator needs 64 more registers than two blocks per CU allow,
+// so this variant runs ONE block per CU (up to 512 VGPRs per lane) and hides everything in the shadow of its own
+// MFMAs instead of behind a second block.  A bf16 MFMA occupies the matrix pipe for 32 cycles but issues in ~4; an
+// in-order wave keeps the pipe full only if at most ~5 other instructions sit between two MFMAs
+// (MI355X guide), so the whole kernel is written as 24 "units" per tap = one MFMA + a thin slice of other work,
+// fenced by sched_barrier(0) so that hipcc keeps the order:
+//   * x tile double-buffered in LDS: the next chunk is transformed (affine, SiLU, split, pack) as 16 two-channel
+//     pieces cut into five slices each (taps 1..6, one slice every other unit) and written straight into the other
+//     buffer; all four waves run the same code (the halo-column lanes load the aligned quad that holds their column
+//     and send the three pixels they do not need to a dump column of the tile);
+//   * weights go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write) into a ring of
+//     four (chunk, kernel row) stages, issued three stages ahead, five 1 KiB pieces per wave and stage;
+//   * operand fragments of the next tap are read during the first 12 units of a tap, across stage and chunk
+//     boundaries;
+//   * one s_barrier per stage, after the stage's first tap: it publishes the next stage's weights (every wave
+//     first waits for its own DMA pieces with a counted vmcnt) and, in the last stage of a chunk, the next x tile.
+namespace x3s {
+using namespace x3;
+constexpr int XS2 = 67;                  // 66 columns + 1 dump column (never read)
+constexpr int XPL2 = NG * XR * XS2;      // entries per plane
+constexpr int XBYTES2 = 3 * XPL2 * 16;   // 38592
+constexpr int RING = 4;
+constexpr int WB0 = 2 * XBYTES2;         // [x buffer 0][x buffer 1][weight ring]
+constexpr int LDS2 = WB0 + RING * WBYTES;  // 150912
+}  // namespace x3s
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;  // M0 = wave-uniform LDS base of the 1 KiB piece; lane i lands at base + 16 i
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ void dma16s(const void* gbase, unsigned voff, unsigned lds_dst) {  // wave-uniform base + lane offset
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+template <int PRO>
+__global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvParams p) {
+    using namespace x3s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int nTw = (W + TW - 1) / TW, nTh = (H + TH - 1) / TH;
+    const int nCoT = p.Cout / CO_T;
+    int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = L % nCoT;
+    L /= nCoT;
+    const int tw = L % nTw;
+    L /= nTw;
+    const int th = L % nTh;
+    const int b = L / nTh;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (p.prof) t0 = __builtin_amdgcn_s_memtime();
+
+    // ---- x staging unit of this thread: one aligned quad (8 channels x 4 pixels) of one tile row ----
+    // threads 0..191: interior quads, all four pixels stored; threads 192..215: the quad that holds a halo column
+    // (left: its last pixel, right: its first), the other three pixels go to the dump column; threads 216..255 repeat
+    // unit 215 (same data, same place).
+    int s_row, s_g, gc;
+    unsigned dsto[4];  // byte offset of pixel e's plane-0 entry within an x buffer
+    if (tid < 192) {
+        s_row = tid >> 5;
+        s_g = (tid >> 4) & 1;
+        gc = tw * TW + (tid & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsto[e] = (unsigned)(((s_g * XR + s_row) * XS2 + 1 + (tid & 15) * 4 + e) * 16);
+    } else {
+        const int u = tid - 192 < 24 ? tid - 192 : 23;
+        s_row = u >> 2;
+        s_g = (u >> 1) & 1;
+        const bool right = u & 1;
+        gc = right ? tw * TW + TW : tw * TW - 4;
+        const unsigned rowb = (unsigned)((s_g * XR + s_row) * XS2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsto[e] = (rowb + (right ? (e == 0 ? XS2 - 2 : XS2 - 1) : (e == 3 ? 0 : XS2 - 1))) * 16;
+    }
+    if (gc < 0) gc += W;
+    while (gc >= W) gc -= W;  // azimuth is periodic; also covers tiles overhanging a narrow image
+    const int gr = th * TH + s_row - 1;
+    const bool s_ok = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
+    const long s_goff = (long)s_g * 8 * HW + (s_ok ? gr * W + gc : 0);
+
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
+    const int nchunks = p.Cin / CK, nstages = 3 * nchunks;
+    const size_t wstage0 = (size_t)cot * nchunks * 3;
+    const float* xb0 = p.x.p0 + b * p.x.bs0;
+    const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
+    const int c0 = p.x.c0;
+    const float* affb = PRO != PRO_NONE ? reinterpret_cast<const float*>(p.aff) + ((size_t)b * p.Cin + s_g * 8) * 2 : nullptr;
+
+    f32x4 raw[8];       // 8 channels x 4 pixels
+    f32x4 ad4[4];       // (a, d) of the 8 channels
+    // Two transform streams run interleaved (X: pixels 0,1; Y: pixels 2,3), each with one channel pair in flight cut
+    // into 14 micro-slices of two INDEPENDENT instructions, one micro-slice per unit: a dependent VALU chain inside
+    // one MFMA shadow would stall the wave's in-order issue beyond it.
+    // (plain scalars, not a struct array: hipcc parks an indexed struct array in scratch memory)
+    float xv0 = 0.f, xv1 = 0.f, xm0 = 0.f, xm1 = 0.f, yv0 = 0.f, yv1 = 0.f, ym0 = 0.f, ym1 = 0.f;
+    unsigned xpk[3][4], ypk[3][4];  // the three planes of the pixel being transformed (4 channel pairs each)
+
+    // raw-load pieces (12 per chunk): i < 8 pixel quads, i >= 8 the folded GroupNorm affine
+    const float* xq = nullptr;
+    const f32x4* aq = nullptr;
+    auto load_setup = [&](int ci0) __attribute__((always_inline)) {
+        xq = (ci0 >= c0 ? xb1 + (long)(ci0 - c0) * HW : xb0 + (long)ci0 * HW) + s_goff;
+        if (PRO != PRO_NONE) aq = reinterpret_cast<const f32x4*>(affb + (size_t)ci0 * 2);
+    };
+    auto load_piece = [&](int i) __attribute__((always_inline)) {
+        if (i < 8)
+            raw[i] = *reinterpret_cast<const f32x4*>(xq + (long)i * HW);
+        else if (PRO != PRO_NONE) {
+            const f32x4 v = aq[i - 8];  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
+            ad4[i - 8] = s_ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // micro-slice `sl` (0..13) of channel pair k = 4*pixel + pair (same arithmetic as silu_f() / split3_pk())
+    auto xf = [&](float& qv0, float& qv1, float& qm0, float& qm1, unsigned (&qpk)[3][4], int k, int sl) __attribute__((always_inline)) {
+        const int e = k >> 2, i2 = k & 3;
+        constexpr bool silu = PRO == PRO_AFFINE_SILU;
+        if (sl == 0) {
+            qv0 = raw[2 * i2][e];
+            qv1 = raw[2 * i2 + 1][e];
+            if (PRO != PRO_NONE) {
+                qv0 = qv0 * ad4[i2][0] + ad4[i2][1];
+                qv1 = qv1 * ad4[i2][2] + ad4[i2][3];
+            }
+        } else if (sl == 1) {
+            if (silu) { qm0 = qv0 * -1.4426950408889634f; qm1 = qv1 * -1.4426950408889634f; }
+        } else if (sl == 2) {
+            if (silu) { qm0 = __builtin_amdgcn_exp2f(qm0); qm1 = __builtin_amdgcn_exp2f(qm1); }
+        } else if (sl == 3) {
+            if (silu) { qm0 = 1.0f + qm0; qm1 = 1.0f + qm1; }
+        } else if (sl == 4) {
+            if (silu) { qm0 = __builtin_amdgcn_rcpf(qm0); qm1 = __builtin_amdgcn_rcpf(qm1); }
+        } else if (sl == 5) {
+            if (silu) { qv0 *= qm0; qv1 *= qm1; }
+        } else if (sl == 6) {
+            if (PRO == PRO_NONE) {
+                qv0 = s_ok ? qv0 : 0.f;
+                qv1 = s_ok ? qv1 : 0.f;
+            }
+        } else if (sl == 7) {
+            qpk[0][i2] = cvt_pk_bf16(qv0, qv1);
+        } else if (sl == 8) {
+            qm0 = __uint_as_float(qpk[0][i2] << 16);
+            qm1 = __uint_as_float(qpk[0][i2] & 0xffff0000u);
+        } else if (sl == 9) {
+            qv0 -= qm0;
+            qv1 -= qm1;
+        } else if (sl == 10) {
+            qpk[1][i2] = cvt_pk_bf16(qv0, qv1);
+        } else if (sl == 11) {
+            qm0 = __uint_as_float(qpk[1][i2] << 16);
+            qm1 = __uint_as_float(qpk[1][i2] & 0xffff0000u);
+        } else if (sl == 12) {
+            qv0 -= qm0;
+            qv1 -= qm1;
+        } else {
+            qpk[2][i2] = cvt_pk_bf16(qv0, qv1);
+        }
+    };
+    auto xf_write = [&](const unsigned (&qpk)[3][4], unsigned char* buf, int e, int pl) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(buf + dsto[e] + pl * (XPL2 * 16)) = u32x4{qpk[pl][0], qpk[pl][1], qpk[pl][2], qpk[pl][3]};
+    };
+    // weights of stage s -> ring slot s % RING: 18 pieces of 1 KiB; every wave issues 5 (the surplus ones repeat piece
+    // 17: same data, same place) so that the vmcnt bookkeeping is the same in all waves
+    unsigned dma_v[5], dma_l[5];  // per-lane byte offset within a stage / LDS base of the piece (ring slot 0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int j = wave + 4 * i;
+        j = j < 18 ? j : 17;
+        dma_v[i] = (unsigned)(j * 1024 + lane * 16);
+        dma_l[i] = lds0 + WB0 + j * 1024;
+    }
+    const unsigned char* wtile = wsrc + wstage0 * WBYTES;
+    auto dma_piece = [&](int s, int i) __attribute__((always_inline)) {
+        dma16s(wtile + (size_t)s * WBYTES, dma_v[i], dma_l[i] + (unsigned)((s & (RING - 1)) * WBYTES));
+    };
+
+    unsigned xcur[NR], xnxt[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int s = wave * NR + n;
+        xcur[n] = lds0 + (unsigned)(((hi * XR + (s >> 1)) * XS2 + (s & 1) * 32 + l31) * 16);
+        xnxt[n] = xcur[n] + XBYTES2;
+    }
+    const unsigned lds_w0 = lds0 + WB0 + (unsigned)((hi * CO_T + l31) * 16);
+
+    // Two-level accumulation: every 64 input channels (576 products) acc is flushed into acc2 and restarts from C = 0, so
+    // roundoff grows with sqrt(576), not sqrt(9 Cin).  Rounding-bias cancellation (see conv_bf16x3_kernel) rides on it:
+    // odd 64-channel blocks use pre-negated weights and are SUBTRACTED at the flush, so the accumulate-toward-minus-
+    // infinity offset of consecutive blocks has opposite sign in acc2 (Cin/64 is even for every deep layer).
+    f32x16 acc[MR][NR], acc2[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = acc2[m][n][r] = 0.f;
+
+    // ---- prologue: weight stages 0..2 in flight, chunk 0 transformed into x buffer 0, chunk 1's pixels requested ----
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_piece(s < nstages ? s : nstages - 1, i);
+    load_setup(0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_piece(i);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int sl = 0; sl < 14; ++sl) xf(xv0, xv1, xm0, xm1, xpk, k, sl);
+        if ((k & 3) == 3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xf_write(xpk, smem, k >> 2, pl);
+        }
+    }
+    load_setup(nchunks > 1 ? CK : 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_piece(i);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (also chunk 1's pixels: once per block)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (p.prof) t1 = __builtin_amdgcn_s_memtime();
+
+    u32x4 fa[2][3][MR], fb[2][3][NR];
+    // fragment read r (0..11) of tap (ky, tx): plane r/4, then A m0, A m1, B n0, B n1
+    auto frag1 = [&](const unsigned (&xb)[NR], unsigned wb, auto KY, auto TX, auto R, u32x4 (&a)[3][MR], u32x4 (&bb)[3][NR])
+                     __attribute__((always_inline)) {
+        constexpr int ky = decltype(KY)::value, tx = decltype(TX)::value, r = decltype(R)::value;
+        constexpr int pl = r / 4, w = r % 4;
+        if constexpr (w < 2)
+            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                         : "=v"(a[pl][w])
+                         : "v"(wb), "i"(pl * (3 * NG * CO_T * 16) + tx * (NG * CO_T * 16) + w * 512));
+        else
+            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                         : "=v"(bb[pl][w - 2])
+                         : "v"(xb[w - 2]), "i"(pl * (XPL2 * 16) + ky * (XS2 * 16) + tx * 16));
+    };
+    {
+        auto f0 = [&](auto R) __attribute__((always_inline)) { frag1(xcur, lds_w0, ic<0>{}, ic<0>{}, R, fa[0], fb[0]); };
+        f0(ic<0>{}); f0(ic<1>{}); f0(ic<2>{}); f0(ic<3>{}); f0(ic<4>{}); f0(ic<5>{});
+        f0(ic<6>{}); f0(ic<7>{}); f0(ic<8>{}); f0(ic<9>{}); f0(ic<10>{}); f0(ic<11>{});
+    }
+
+    // one tap = 24 units; T = tap within the chunk (ky = T / 3, tx = T % 3), PAR = parity of the chunk
+    auto tap = [&](int c, auto TT, auto PAR) __attribute__((always_inline)) {
+        constexpr int t = decltype(TT)::value, par = decltype(PAR)::value;
+        constexpr int ky = t / 3, tx = t % 3, cur = (par * 9 + t) & 1;
+        constexpr int kyn = t < 8 ? (t + 1) / 3 : 0, txn = t < 8 ? (t + 1) % 3 : 0;  // next tap
+        const int sigma = 3 * c + ky;
+        unsigned char* nbuf = smem + ((c + 1) & 1) * XBYTES2;  // x buffer being filled (chunk c+1)
+        if (tx == 1) {
+            // B_sigma: everybody is past tap (sigma, 0).  Before it: this wave's pieces of stage sigma+1 have landed
+            // (only stage sigma+2's five may still be in flight) and its x-tile writes are done.
+#ifndef X3S_NO_BARRIER
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            asm volatile("" ::: "memory");
+            if (ky == 0) {
+                // hipcc waits for the raw pixels (its own loads) at their first use with a vmcnt that knows nothing
+                // about the DMA pieces issued below, i.e. it would wait for those too: take that wait here
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(raw[i]));
+                if (PRO != PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ad4[j]));
+                }
+            }
+        } else {
+#ifdef X3S_LGKM_RELAX
+            asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tap's fragments (issued a tap ago)
+#endif
+        }
+        const unsigned wbn = lds_w0 + (unsigned)(((t < 8 ? sigma + (kyn != ky ? 1 : 0) : sigma + 1) & (RING - 1)) * WBYTES);
+        int sdma = sigma + 3;
+        sdma = sdma < nstages ? sdma : nstages - 1;  // past the end: repeat the last stage (harmless, keeps vmcnt uniform)
+        if (t == 7) load_setup((c + 2 < nchunks ? c + 2 : nchunks - 1) * CK);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PI[6] = {2, 0, 1, 1, 0, 0}, PJ[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int q = i / 4, m = (i / 2) & 1, n = i & 1;
+            f32x16& ac = acc[m][n];
+            const bf16x8 fra = __builtin_bit_cast(bf16x8, fa[cur][PI[q]][m]), frb = __builtin_bit_cast(bf16x8, fb[cur][PJ[q]][n]);
+            if (t == 0 && i < 4 && (c & 3) == 0) {  // first product of a 64-channel block: start from zero
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra, frb, zero, 0, 0, 0);
+            } else {
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra, frb, ac, 0, 0, 0);
+            }
+            // ---- at most a handful of other instructions in the shadow of this MFMA ----
+            if (i < 12) {  // next tap's fragments (the next chunk's first tap reads the other x buffer)
+                auto fr = [&](auto R) __attribute__((always_inline)) {
+                    if (t < 8)
+                        frag1(xcur, wbn, ic<kyn>{}, ic<txn>{}, R, fa[cur ^ 1], fb[cur ^ 1]);
+                    else
+                        frag1(xnxt, wbn, ic<0>{}, ic<0>{}, R, fa[cur ^ 1], fb[cur ^ 1]);
+                };
+                if (i == 0) fr(ic<0>{});
+                if (i == 1) fr(ic<1>{});
+                if (i == 2) fr(ic<2>{});
+                if (i == 3) fr(ic<3>{});
+                if (i == 4) fr(ic<4>{});
+                if (i == 5) fr(ic<5>{});
+                if (i == 6) fr(ic<6>{});
+                if (i == 7) fr(ic<7>{});
+                if (i == 8) fr(ic<8>{});
+                if (i == 9) fr(ic<9>{});
+                if (i == 10) fr(ic<10>{});
+                if (i == 11) fr(ic<11>{});
+            }
+#ifndef X3S_NO_DMA
+            if (tx == 1 && (i & 3) == 1 && i < 20) dma_piece(sdma, i >> 2);  // into the ring slot of stage sigma-1
+#endif
+#ifndef X3S_NO_XF
+            if (t >= 1 && t <= 6) {  // transform of chunk c+1: 144 slots; stream X pairs 0..7, stream Y pairs 8..15,
+                const int slot = (t - 1) * 24 + i, j = slot / 18, off = slot % 18;  // pair j of a stream in slots 18j..18j+17
+                if (off < 14) {
+                    xf(xv0, xv1, xm0, xm1, xpk, j, off);
+                    xf(yv0, yv1, ym0, ym1, ypk, 8 + j, off);
+                } else if ((j & 3) == 3 && off < 17) {
+                    xf_write(xpk, nbuf, j >> 2, off - 14);
+                    xf_write(ypk, nbuf, (8 + j) >> 2, off - 14);
+                }
+            }
+#endif
+            if (t == 7 && i >= 12) load_piece(i - 12);  // raw pixels of the chunk after next
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chunk = [&](int c, auto PAR) __attribute__((always_inline)) {
+        tap(c, ic<0>{}, PAR); tap(c, ic<1>{}, PAR); tap(c, ic<2>{}, PAR);
+        tap(c, ic<3>{}, PAR); tap(c, ic<4>{}, PAR); tap(c, ic<5>{}, PAR);
+        tap(c, ic<6>{}, PAR); tap(c, ic<7>{}, PAR); tap(c, ic<8>{}, PAR);
+#ifndef X3S_NO_FLIP
+        if ((c & 3) == 3) {  // flush (acc restarts from C = 0 in the next chunk: no zeroing pass)
+            if (c & 4) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[m][n][r] -= acc[m][n][r];
+            } else {
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[m][n][r] += acc[m][n][r];
+            }
+        }
+#endif
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const unsigned tswap = xcur[n];
+            xcur[n] = xnxt[n];
+            xnxt[n] = tswap;
+        }
+    };
+
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, ic<0>{});
+        chunk(c + 1, ic<1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // surplus DMA pieces / prefetched fragments must not outlive the block
+    if (p.prof) t2 = __builtin_amdgcn_s_memtime();
+
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;  // everything was flushed (Cin % 64 == 0)
+    conv_epilogue<4, TH, TW, MR, NR, true>(p, acc, acc2, b, th, tw, nTw, cot * CO_T, wave, lane);
+
+    if (p.prof && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.prof + (size_t)blockIdx.x * 8;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+        o[3] = __builtin_amdgcn_s_memtime();
         o[4] = o[5] = o[6] = 0;
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
     }
@@ -299,7 +721,7 @@ __global__ __launch_bounds__(256, ACC2 ? 1 : 2) void conv_bf16x3_kernel(const Co
 
 // ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane][tap in row][group][co 64][8 ch] bf16 ----
 __global__ void pack_conv_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout,
-                                        int Cin, long total) {
+                                        int Cin, long total, int sign_shift) {
     using namespace x3;
     const int nchunks = Cin / CK;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -321,14 +743,23 @@ __global__ void pack_conv_bf16x3_kernel(const float* __restrict__ w, unsigned sh
         const int co = cot * CO_T + col, ci = c * CK + g * 8 + ch;
         unsigned u[3];
         float v = w[((long)co * Cin + ci) * 9 + ky * 3 + tx];
-        if (c & 1) v = -v;  // odd chunks are accumulated with flipped sign (see the kernel: rounding-bias cancellation)
+        if ((c >> sign_shift) & 1) v = -v;  // rounding-bias cancellation: chunk pairs (shallow) / 64-channel blocks (deep) of alternating sign
         split3_pk(v, v, u[0], u[1], u[2]);
         dst[i] = (unsigned short)(u[pl] & 0xffffu);
     }
 }
 
+static int shallow_sign_shift() {  // shallow layers flip the accumulator every 2^shift chunks
+    static const int v = [] { const char* e = getenv("R2DM_X3_SHALLOW_SHIFT"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+// long reductions (K = 9*Cin > 1152): two-level accumulation, stream kernel, block-wise sign pattern
+static bool conv_bf16x3_deep(int Cin) { return Cin > 128; }
+
 bool conv_bf16x3_supported(int Cin, int Cout, int taps) {
-    return taps == 9 && Cin % (2 * x3::CK) == 0 && Cout % x3::CO_T == 0;  // an even number of 16-channel chunks
+    // an even number of 32-channel chunk pairs (shallow) / of 64-channel blocks (deep): the sign pattern must balance
+    return taps == 9 && Cout % x3::CO_T == 0 && Cin % (conv_bf16x3_deep(Cin) ? 128 : 64) == 0;
 }
 
 long conv_bf16x3_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * 3 / 2; }
@@ -336,7 +767,8 @@ long conv_bf16x3_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 
 hipError_t launch_pack_conv_bf16x3(const float* w, float* dst, int Cout, int Cin, hipStream_t s) {
     const long total = (long)Cout * Cin * 9 * 3;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total);
+    pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total,
+                                                   conv_bf16x3_deep(Cin) ? 2 : shallow_sign_shift());
     return hipGetLastError();
 }
 
@@ -356,16 +788,36 @@ static hipError_t launch_x3(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int PRO>
+static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
+    auto kern = conv_bf16x3_stream_kernel<PRO>;
+    constexpr int lds = x3s::LDS2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nTw = (p.W + 63) / 64, nTh = (p.H + 3) / 4, nCoT = p.Cout / x3::CO_T;
+    const long nblk = (long)nCoT * nTw * nTh * p.B;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
     if (!conv_bf16x3_supported(p.Cin, p.Cout, p.taps)) return hipErrorInvalidValue;
+    if (conv_bf16x3_deep(p.Cin) && p.Cin % 128) return hipErrorInvalidValue;  // an even number of 64-channel blocks
     if (p.x.p1 && p.x.c0 % x3::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.H * (long)p.W * 16 >= (1L << 31) || p.W % 4) return hipErrorInvalidValue;
-    const bool deep = p.Cin > 128;  // long reductions (K = 9*Cin > 1152) get the two-level accumulator
+    const bool deep = conv_bf16x3_deep(p.Cin);
+    ConvParams q = p;
+    q.sign_shift = shallow_sign_shift();
     switch (p.prologue) {
-        case PRO_NONE: return deep ? launch_x3<PRO_NONE, true>(p, s) : launch_x3<PRO_NONE, false>(p, s);
-        case PRO_AFFINE: return deep ? launch_x3<PRO_AFFINE, true>(p, s) : launch_x3<PRO_AFFINE, false>(p, s);
-        case PRO_AFFINE_SILU: return deep ? launch_x3<PRO_AFFINE_SILU, true>(p, s) : launch_x3<PRO_AFFINE_SILU, false>(p, s);
+        case PRO_NONE: return !deep ? launch_x3<PRO_NONE, false>(q, s) : launch_x3_stream<PRO_NONE>(p, s);
+        case PRO_AFFINE: return !deep ? launch_x3<PRO_AFFINE, false>(q, s) : launch_x3_stream<PRO_AFFINE>(p, s);
+        case PRO_AFFINE_SILU: return !deep ? launch_x3<PRO_AFFINE_SILU, false>(q, s) : launch_x3_stream<PRO_AFFINE_SILU>(p, s);
     }
     return hipErrorInvalidValue;
 }

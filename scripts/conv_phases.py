@@ -21,9 +21,10 @@ for n in os.environ.get("SHAPES", "L1_64_64").split(","):
         _lib.check(L.r2dm_conv2d_ring(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), packed.data_ptr(), _lib.ptr(aff), pro, _lib.ptr(r), _lib.ptr(sc), y.data_ptr(), B, cin, cout, h, w, k, st))
         torch.cuda.synchronize()
     p = prof.cpu()
-    p = p[p[:, 3] > 0].double()
+    pi = p[p[:, 3] > 0]; p = pi.double()
     tot = (p[:, 3] - p[:, 0]).mean()
     ml = (p[:, 2] - p[:, 1]).mean()
     print(f"{n}: blocks {len(p)}  block {tot:.0f} cycles = prologue {(p[:,1]-p[:,0]).mean():.0f} + main loop {ml:.0f} + epilogue {(p[:,3]-p[:,2]).mean():.0f}")
-    for name, col in (("issue next chunk's loads", 4), ("mfma + lds reads + interleaved staging", 5), ("barrier", 6)):
-        print(f"   {name:40s} {p[:, col].mean():9.0f} cycles ({p[:, col].mean() / ml * 100:5.1f}% of main loop)")
+    bar = (pi[:, 6] & 0xffffffff).double(); xf = (pi[:, 6] >> 32).double()
+    for name, v in (("issue next loads", p[:, 4]), ("mfma + lds reads (+ staging / weight stores)", p[:, 5]), ("barrier", bar), ("chunk-boundary transform (bf16x3)", xf)):
+        print(f"   {name:46s} {v.mean():9.0f} cycles ({v.mean() / ml * 100:5.1f}% of main loop)")

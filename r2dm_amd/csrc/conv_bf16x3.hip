@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
 
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
     const int nchunks = p.Cin / CK, nstages = 3 * nchunks;
+    const int bmask = (1 << p.sign_shift) - 1;  // accumulation block = 2^sign_shift chunks (64 channels for the deep layers)
     const size_t wstage0 = (size_t)cot * nchunks * 3;
     const float* xb0 = p.x.p0 + b * p.x.bs0;
     const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
             const int q = i / 4, m = (i / 2) & 1, n = i & 1;
             f32x16& ac = acc[m][n];
             const bf16x8 fra = __builtin_bit_cast(bf16x8, fa[cur][PI[q]][m]), frb = __builtin_bit_cast(bf16x8, fb[cur][PJ[q]][n]);
-            if (t == 0 && i < 4 && (c & 3) == 0) {  // first product of a 64-channel block: start from zero
+            if (t == 0 && i < 4 && (c & bmask) == 0) {  // first product of a block: start from zero
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra, frb, zero, 0, 0, 0);
             } else {
@@ -666,8 +667,8 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         tap(c, ic<3>{}, PAR); tap(c, ic<4>{}, PAR); tap(c, ic<5>{}, PAR);
         tap(c, ic<6>{}, PAR); tap(c, ic<7>{}, PAR); tap(c, ic<8>{}, PAR);
 #ifndef X3S_NO_FLIP
-        if ((c & 3) == 3) {  // flush (acc restarts from C = 0 in the next chunk: no zeroing pass)
-            if (c & 4) {
+        if ((c & bmask) == bmask) {  // flush (acc restarts from C = 0 in the next chunk: no zeroing pass)
+            if (c & (bmask + 1)) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -719,6 +720,335 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     }
 }
 
+// ---- shallow variant of the stream kernel: two blocks per CU, single x tile, weight ring of two stages -----------
+// Cin <= 128: K is short, so prologue / epilogue / chunk-boundary phases of one block must be covered by a second
+// block on the same CU; 75 KB of LDS and 256 registers per block.  The tap stream (MFMA + fragment reads + DMA
+// pieces + raw pixel loads interleaved unit by unit) is the one of conv_bf16x3_stream_kernel; the transform of the
+// next chunk runs at the chunk boundary because the single x tile is free only then.
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvParams p) {
+    using namespace x3s;
+    constexpr int RING2 = 2, WB1 = XBYTES2;  // [x tile][weight ring of two stages]: 75456 bytes, two blocks per CU
+    constexpr int NL = PRO != PRO_NONE ? 12 : 8;  // VMEM loads per chunk of raw pixels (+ folded affine)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int nTw = (W + TW - 1) / TW, nTh = (H + TH - 1) / TH;
+    const int nCoT = p.Cout / CO_T;
+    int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = L % nCoT;
+    L /= nCoT;
+    const int tw = L % nTw;
+    L /= nTw;
+    const int th = L % nTh;
+    const int b = L / nTh;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (p.prof) t0 = __builtin_amdgcn_s_memtime();
+
+    // ---- x staging unit of this thread: one aligned quad (8 channels x 4 pixels) of one tile row ----
+    // threads 0..191: interior quads, all four pixels stored; threads 192..215: the quad that holds a halo column
+    // (left: its last pixel, right: its first), the other three pixels go to the dump column; threads 216..255 repeat
+    // unit 215 (same data, same place).
+    int s_row, s_g, gc;
+    unsigned dsto[4];  // byte offset of pixel e's plane-0 entry within an x buffer
+    if (tid < 192) {
+        s_row = tid >> 5;
+        s_g = (tid >> 4) & 1;
+        gc = tw * TW + (tid & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsto[e] = (unsigned)(((s_g * XR + s_row) * XS2 + 1 + (tid & 15) * 4 + e) * 16);
+    } else {
+        const int u = tid - 192 < 24 ? tid - 192 : 23;
+        s_row = u >> 2;
+        s_g = (u >> 1) & 1;
+        const bool right = u & 1;
+        gc = right ? tw * TW + TW : tw * TW - 4;
+        const unsigned rowb = (unsigned)((s_g * XR + s_row) * XS2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsto[e] = (rowb + (right ? (e == 0 ? XS2 - 2 : XS2 - 1) : (e == 3 ? 0 : XS2 - 1))) * 16;
+    }
+    if (gc < 0) gc += W;
+    while (gc >= W) gc -= W;  // azimuth is periodic; also covers tiles overhanging a narrow image
+    const int gr = th * TH + s_row - 1;
+    const bool s_ok = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
+    const long s_goff = (long)s_g * 8 * HW + (s_ok ? gr * W + gc : 0);
+
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
+    const int nchunks = p.Cin / CK, nstages = 3 * nchunks;
+    const size_t wstage0 = (size_t)cot * nchunks * 3;
+    const float* xb0 = p.x.p0 + b * p.x.bs0;
+    const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
+    const int c0 = p.x.c0;
+    const float* affb = PRO != PRO_NONE ? reinterpret_cast<const float*>(p.aff) + ((size_t)b * p.Cin + s_g * 8) * 2 : nullptr;
+
+    f32x4 raw[8];       // 8 channels x 4 pixels
+    f32x4 ad4[4];       // (a, d) of the 8 channels
+    // Two transform streams run interleaved (X: pixels 0,1; Y: pixels 2,3), each with one channel pair in flight cut
+    // into 14 micro-slices of two INDEPENDENT instructions, one micro-slice per unit: a dependent VALU chain inside
+    // one MFMA shadow would stall the wave's in-order issue beyond it.
+    // (plain scalars, not a struct array: hipcc parks an indexed struct array in scratch memory)
+    float xv0 = 0.f, xv1 = 0.f, xm0 = 0.f, xm1 = 0.f;
+    unsigned xpk[3][4];  // the three planes of the pixel being transformed (4 channel pairs each)
+
+    // raw-load pieces (12 per chunk): i < 8 pixel quads, i >= 8 the folded GroupNorm affine
+    const float* xq = nullptr;
+    const f32x4* aq = nullptr;
+    auto load_setup = [&](int ci0) __attribute__((always_inline)) {
+        xq = (ci0 >= c0 ? xb1 + (long)(ci0 - c0) * HW : xb0 + (long)ci0 * HW) + s_goff;
+        if (PRO != PRO_NONE) aq = reinterpret_cast<const f32x4*>(affb + (size_t)ci0 * 2);
+    };
+    auto load_piece = [&](int i) __attribute__((always_inline)) {
+        if (i < 8)
+            raw[i] = *reinterpret_cast<const f32x4*>(xq + (long)i * HW);
+        else if (PRO != PRO_NONE) {
+            const f32x4 v = aq[i - 8];  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
+            ad4[i - 8] = s_ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // micro-slice `sl` (0..13) of channel pair k = 4*pixel + pair (same arithmetic as silu_f() / split3_pk())
+    auto xf = [&](float& qv0, float& qv1, float& qm0, float& qm1, unsigned (&qpk)[3][4], int k, int sl) __attribute__((always_inline)) {
+        const int e = k >> 2, i2 = k & 3;
+        constexpr bool silu = PRO == PRO_AFFINE_SILU;
+        if (sl == 0) {
+            qv0 = raw[2 * i2][e];
+            qv1 = raw[2 * i2 + 1][e];
+            if (PRO != PRO_NONE) {
+                qv0 = qv0 * ad4[i2][0] + ad4[i2][1];
+                qv1 = qv1 * ad4[i2][2] + ad4[i2][3];
+            }
+        } else if (sl == 1) {
+            if (silu) { qm0 = qv0 * -1.4426950408889634f; qm1 = qv1 * -1.4426950408889634f; }
+        } else if (sl == 2) {
+            if (silu) { qm0 = __builtin_amdgcn_exp2f(qm0); qm1 = __builtin_amdgcn_exp2f(qm1); }
+        } else if (sl == 3) {
+            if (silu) { qm0 = 1.0f + qm0; qm1 = 1.0f + qm1; }
+        } else if (sl == 4) {
+            if (silu) { qm0 = __builtin_amdgcn_rcpf(qm0); qm1 = __builtin_amdgcn_rcpf(qm1); }
+        } else if (sl == 5) {
+            if (silu) { qv0 *= qm0; qv1 *= qm1; }
+        } else if (sl == 6) {
+            if (PRO == PRO_NONE) {
+                qv0 = s_ok ? qv0 : 0.f;
+                qv1 = s_ok ? qv1 : 0.f;
+            }
+        } else if (sl == 7) {
+            qpk[0][i2] = cvt_pk_bf16(qv0, qv1);
+        } else if (sl == 8) {
+            qm0 = __uint_as_float(qpk[0][i2] << 16);
+            qm1 = __uint_as_float(qpk[0][i2] & 0xffff0000u);
+        } else if (sl == 9) {
+            qv0 -= qm0;
+            qv1 -= qm1;
+        } else if (sl == 10) {
+            qpk[1][i2] = cvt_pk_bf16(qv0, qv1);
+        } else if (sl == 11) {
+            qm0 = __uint_as_float(qpk[1][i2] << 16);
+            qm1 = __uint_as_float(qpk[1][i2] & 0xffff0000u);
+        } else if (sl == 12) {
+            qv0 -= qm0;
+            qv1 -= qm1;
+        } else {
+            qpk[2][i2] = cvt_pk_bf16(qv0, qv1);
+        }
+    };
+    auto xf_write = [&](const unsigned (&qpk)[3][4], unsigned char* buf, int e, int pl) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(buf + dsto[e] + pl * (XPL2 * 16)) = u32x4{qpk[pl][0], qpk[pl][1], qpk[pl][2], qpk[pl][3]};
+    };
+    // weights of stage s -> ring slot s % RING: 18 pieces of 1 KiB; every wave issues 5 (the surplus ones repeat piece
+    // 17: same data, same place) so that the vmcnt bookkeeping is the same in all waves
+    unsigned dma_v[5], dma_l[5];  // per-lane byte offset within a stage / LDS base of the piece (ring slot 0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int j = wave + 4 * i;
+        j = j < 18 ? j : 17;
+        dma_v[i] = (unsigned)(j * 1024 + lane * 16);
+        dma_l[i] = lds0 + WB1 + j * 1024;
+    }
+    const unsigned char* wtile = wsrc + wstage0 * WBYTES;
+    auto dma_piece = [&](int s, int i) __attribute__((always_inline)) {
+        dma16s(wtile + (size_t)s * WBYTES, dma_v[i], dma_l[i] + (unsigned)((s & (RING2 - 1)) * WBYTES));
+    };
+
+    unsigned xcur[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int s = wave * NR + n;
+        xcur[n] = lds0 + (unsigned)(((hi * XR + (s >> 1)) * XS2 + (s & 1) * 32 + l31) * 16);
+    }
+    const unsigned lds_w0 = lds0 + WB1 + (unsigned)((hi * CO_T + l31) * 16);
+
+    f32x16 acc[MR][NR], accd[1][1];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // ---- prologue: weight stages 0 and 1 in flight, chunk 0 transformed into the x tile ----
+    auto transform_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int sl = 0; sl < 14; ++sl) xf(xv0, xv1, xm0, xm1, xpk, k, sl);
+            if ((k & 3) == 3) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xf_write(xpk, smem, k >> 2, pl);
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_piece(s < nstages ? s : nstages - 1, i);
+    load_setup(0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_piece(i);
+    transform_all();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (p.prof) t1 = __builtin_amdgcn_s_memtime();
+
+    u32x4 fa[2][3][MR], fb[2][3][NR];
+    // fragment read r (0..11) of tap (ky, tx): plane r/4, then A m0, A m1, B n0, B n1
+    auto frag1 = [&](const unsigned (&xb)[NR], unsigned wb, auto KY, auto TX, auto R, u32x4 (&a)[3][MR], u32x4 (&bb)[3][NR])
+                     __attribute__((always_inline)) {
+        constexpr int ky = decltype(KY)::value, tx = decltype(TX)::value, r = decltype(R)::value;
+        constexpr int pl = r / 4, w = r % 4;
+        if constexpr (w < 2)
+            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                         : "=v"(a[pl][w])
+                         : "v"(wb), "i"(pl * (3 * NG * CO_T * 16) + tx * (NG * CO_T * 16) + w * 512));
+        else
+            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                         : "=v"(bb[pl][w - 2])
+                         : "v"(xb[w - 2]), "i"(pl * (XPL2 * 16) + ky * (XS2 * 16) + tx * 16));
+    };
+    {
+        auto f0 = [&](auto R) __attribute__((always_inline)) { frag1(xcur, lds_w0, ic<0>{}, ic<0>{}, R, fa[0], fb[0]); };
+        f0(ic<0>{}); f0(ic<1>{}); f0(ic<2>{}); f0(ic<3>{}); f0(ic<4>{}); f0(ic<5>{});
+        f0(ic<6>{}); f0(ic<7>{}); f0(ic<8>{}); f0(ic<9>{}); f0(ic<10>{}); f0(ic<11>{});
+    }
+
+    // one tap = 24 units (one MFMA + a thin slice of other work each, see conv_bf16x3_stream_kernel)
+    auto tap = [&](int c, auto TT, auto PAR) __attribute__((always_inline)) {
+        constexpr int t = decltype(TT)::value, par = decltype(PAR)::value;
+        constexpr int ky = t / 3, tx = t % 3, cur = (par * 9 + t) & 1;
+        constexpr int kyn = t < 8 ? (t + 1) / 3 : 0, txn = t < 8 ? (t + 1) % 3 : 0;  // next tap
+        const int sigma = 3 * c + ky;
+        if (tx == 2) {
+            // B'_sigma: this wave's pieces of stage sigma+1 have landed (only the raw pixel loads issued during this chunk's
+            // first tap may still be in flight) and every wave has its fragments of tap (sigma, 2) in registers: stage
+            // sigma+1 may be read, ring slot sigma % 2 may be overwritten.
+            if (ky == 0)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ky == 2) {  // hipcc's own wait for the raw pixels would also wait for the DMA pieces issued below
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(raw[i]));
+                if (PRO != PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ad4[j]));
+                }
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tap's fragments (issued a tap ago)
+        }
+        const unsigned wbn = lds_w0 + (unsigned)(((kyn != ky ? sigma + 1 : sigma) & (RING2 - 1)) * WBYTES);
+        int sdma = sigma + 2;
+        sdma = sdma < nstages ? sdma : nstages - 1;  // past the end: repeat the last stage (harmless, keeps vmcnt uniform)
+        if (t == 0) load_setup((c + 1 < nchunks ? c + 1 : nchunks - 1) * CK);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PI[6] = {2, 0, 1, 1, 0, 0}, PJ[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int q = i / 4, m = (i / 2) & 1, n = i & 1;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][PI[q]][m]),
+                                                                __builtin_bit_cast(bf16x8, fb[cur][PJ[q]][n]), acc[m][n], 0, 0, 0);
+            if (i < 12 && t < 8) {  // next tap's fragments (the next chunk's first tap waits for the new x tile)
+                auto fr = [&](auto R) __attribute__((always_inline)) {
+                    frag1(xcur, wbn, ic<kyn>{}, ic<txn>{}, R, fa[cur ^ 1], fb[cur ^ 1]);
+                };
+                if (i == 0) fr(ic<0>{});
+                if (i == 1) fr(ic<1>{});
+                if (i == 2) fr(ic<2>{});
+                if (i == 3) fr(ic<3>{});
+                if (i == 4) fr(ic<4>{});
+                if (i == 5) fr(ic<5>{});
+                if (i == 6) fr(ic<6>{});
+                if (i == 7) fr(ic<7>{});
+                if (i == 8) fr(ic<8>{});
+                if (i == 9) fr(ic<9>{});
+                if (i == 10) fr(ic<10>{});
+                if (i == 11) fr(ic<11>{});
+            }
+            if (tx == 2 && (i & 3) == 1 && i < 20) dma_piece(sdma, i >> 2);  // into the ring slot of stage sigma
+            if (t == 0 && i >= 12) load_piece(i - 12);  // raw pixels of the next chunk
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chunk = [&](int c, auto PAR) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value;
+        tap(c, ic<0>{}, PAR); tap(c, ic<1>{}, PAR); tap(c, ic<2>{}, PAR);
+        tap(c, ic<3>{}, PAR); tap(c, ic<4>{}, PAR); tap(c, ic<5>{}, PAR);
+        tap(c, ic<6>{}, PAR); tap(c, ic<7>{}, PAR); tap(c, ic<8>{}, PAR);
+        // rounding-bias cancellation: see conv_bf16x3_kernel
+        if (((c + 1) & ((1 << p.sign_shift) - 1)) == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = -acc[m][n][r];
+        }
+        if (c + 1 < nchunks) {
+            // chunk boundary: the single x tile is rewritten while the other block of this CU owns the matrix pipe
+            __builtin_amdgcn_s_barrier();  // every wave has its last fragments of this chunk in registers
+            asm volatile("" ::: "memory");
+            transform_all();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            constexpr int nb = ((par * 9 + 8) & 1) ^ 1;
+            const unsigned wb0 = lds_w0 + (unsigned)(((3 * c + 3) & (RING2 - 1)) * WBYTES);
+            auto f0 = [&](auto R) __attribute__((always_inline)) { frag1(xcur, wb0, ic<0>{}, ic<0>{}, R, fa[nb], fb[nb]); };
+            f0(ic<0>{}); f0(ic<1>{}); f0(ic<2>{}); f0(ic<3>{}); f0(ic<4>{}); f0(ic<5>{});
+            f0(ic<6>{}); f0(ic<7>{}); f0(ic<8>{}); f0(ic<9>{}); f0(ic<10>{}); f0(ic<11>{});
+        }
+    };
+
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, ic<0>{});
+        chunk(c + 1, ic<1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // surplus DMA pieces / prefetched fragments must not outlive the block
+    if (p.prof) t2 = __builtin_amdgcn_s_memtime();
+
+    conv_epilogue<4, TH, TW, MR, NR, false>(p, acc, accd, b, th, tw, nTw, cot * CO_T, wave, lane);
+
+    if (p.prof && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.prof + (size_t)blockIdx.x * 8;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+        o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = o[5] = o[6] = 0;
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+}
+
 // ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane][tap in row][group][co 64][8 ch] bf16 ----
 __global__ void pack_conv_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout,
                                         int Cin, long total, int sign_shift) {
@@ -749,17 +1079,19 @@ __global__ void pack_conv_bf16x3_kernel(const float* __restrict__ w, unsigned sh
     }
 }
 
-static int shallow_sign_shift() {  // shallow layers flip the accumulator every 2^shift chunks
-    static const int v = [] { const char* e = getenv("R2DM_X3_SHALLOW_SHIFT"); return e ? atoi(e) : 1; }();
+static bool stream_all() {  // experiment: run every layer through the stream kernel
+    static const bool v = getenv("R2DM_X3_STREAM_ALL") != nullptr;
     return v;
 }
 
 // long reductions (K = 9*Cin > 1152): two-level accumulation, stream kernel, block-wise sign pattern
-static bool conv_bf16x3_deep(int Cin) { return Cin > 128; }
+static bool conv_bf16x3_deep(int Cin) { return Cin > 128 || stream_all(); }
+// chunks per sign block = 2^shift: shallow kernel flips every 2 chunks; stream kernel: 64-channel blocks (32 for Cin = 64)
+static int conv_bf16x3_sign_shift(int Cin) { return !conv_bf16x3_deep(Cin) ? 1 : Cin >= 128 ? 2 : 1; }
 
 bool conv_bf16x3_supported(int Cin, int Cout, int taps) {
     // an even number of 32-channel chunk pairs (shallow) / of 64-channel blocks (deep): the sign pattern must balance
-    return taps == 9 && Cout % x3::CO_T == 0 && Cin % (conv_bf16x3_deep(Cin) ? 128 : 64) == 0;
+    return taps == 9 && Cout % x3::CO_T == 0 && Cin % (32 << conv_bf16x3_sign_shift(Cin)) == 0;
 }
 
 long conv_bf16x3_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * 3 / 2; }
@@ -768,7 +1100,7 @@ hipError_t launch_pack_conv_bf16x3(const float* w, float* dst, int Cout, int Cin
     const long total = (long)Cout * Cin * 9 * 3;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total,
-                                                   conv_bf16x3_deep(Cin) ? 2 : shallow_sign_shift());
+                                                   conv_bf16x3_sign_shift(Cin));
     return hipGetLastError();
 }
 
@@ -785,6 +1117,23 @@ static hipError_t launch_x3(const ConvParams& p, hipStream_t s) {
     const int nTw = (p.W + 63) / 64, nTh = (p.H + 3) / 4, nCoT = p.Cout / x3::CO_T;
     const long nblk = (long)nCoT * nTw * nTh * p.B;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), x3::LDS, s, p);
+    return hipGetLastError();
+}
+
+template <int PRO>
+static hipError_t launch_x3_pair(const ConvParams& p, hipStream_t s) {
+    auto kern = conv_bf16x3_pair_kernel<PRO>;
+    constexpr int lds = x3s::XBYTES2 + 2 * x3::WBYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nTw = (p.W + 63) / 64, nTh = (p.H + 3) / 4, nCoT = p.Cout / x3::CO_T;
+    const long nblk = (long)nCoT * nTw * nTh * p.B;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -807,17 +1156,17 @@ static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
 
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
     if (!conv_bf16x3_supported(p.Cin, p.Cout, p.taps)) return hipErrorInvalidValue;
-    if (conv_bf16x3_deep(p.Cin) && p.Cin % 128) return hipErrorInvalidValue;  // an even number of 64-channel blocks
     if (p.x.p1 && p.x.c0 % x3::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.H * (long)p.W * 16 >= (1L << 31) || p.W % 4) return hipErrorInvalidValue;
     const bool deep = conv_bf16x3_deep(p.Cin);
     ConvParams q = p;
-    q.sign_shift = shallow_sign_shift();
+    q.sign_shift = conv_bf16x3_sign_shift(p.Cin);
+    static const bool old_pair = getenv("R2DM_X3_OLDPAIR") != nullptr;  // A/B: boundary-everything kernel
     switch (p.prologue) {
-        case PRO_NONE: return !deep ? launch_x3<PRO_NONE, false>(q, s) : launch_x3_stream<PRO_NONE>(p, s);
-        case PRO_AFFINE: return !deep ? launch_x3<PRO_AFFINE, false>(q, s) : launch_x3_stream<PRO_AFFINE>(p, s);
-        case PRO_AFFINE_SILU: return !deep ? launch_x3<PRO_AFFINE_SILU, false>(q, s) : launch_x3_stream<PRO_AFFINE_SILU>(p, s);
+        case PRO_NONE: return deep ? launch_x3_stream<PRO_NONE>(q, s) : old_pair ? launch_x3<PRO_NONE, false>(q, s) : launch_x3_pair<PRO_NONE>(q, s);
+        case PRO_AFFINE: return deep ? launch_x3_stream<PRO_AFFINE>(q, s) : old_pair ? launch_x3<PRO_AFFINE, false>(q, s) : launch_x3_pair<PRO_AFFINE>(q, s);
+        case PRO_AFFINE_SILU: return deep ? launch_x3_stream<PRO_AFFINE_SILU>(q, s) : old_pair ? launch_x3<PRO_AFFINE_SILU, false>(q, s) : launch_x3_pair<PRO_AFFINE_SILU>(q, s);
     }
     return hipErrorInvalidValue;
 }

@@ -9,28 +9,28 @@ out.append("%-92s %7s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us",
 for r in rows[:18]:
     name = re.sub(r'r2dm::', '', r['Name'])[:92]
     out.append("%-92s %7s %12.3f %10.1f %7.2f" % (name, r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
-conv = [r for r in rows if 'conv_mfma' in r['Name']]
+conv = [r for r in rows if 'conv_' in r['Name'] and 'pack' not in r['Name']]
 tn = sum(float(r['TotalDurationNs']) for r in conv); nc = sum(int(r['Calls']) for r in conv)
-out.append("\nconv_mfma_kernel (all template variants): calls %d  total %.2f ms  average launch %.1f us" % (nc, tn / 1e6, tn / nc / 1e3))
+out.append("\nconvolution kernels (conv_bf16x3_pair / conv_bf16x3_stream / conv_mfma, all template variants): calls %d  total %.2f ms  average launch %.1f us" % (nc, tn / 1e6, tn / nc / 1e3))
 def pmc(fn, cname):
-    v = [float(r['Counter_Value']) for r in csv.DictReader(open(d + fn)) if 'conv_mfma' in r['Kernel_Name'] and r['Counter_Name'] == cname]
+    v = [float(r['Counter_Value']) for r in csv.DictReader(open(d + fn)) if 'conv_' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name'] and r['Counter_Name'] == cname]
     return sum(v) / len(v), len(v)
 f, nf = pmc('bench_fetch_counter_collection.csv', 'FETCH_SIZE'); w, nw = pmc('bench_write_counter_collection.csv', 'WRITE_SIZE')
 j = json.load(open(d + 'bench_n1.json'))
 dk = j['roofline']['dominant_kernel']
 out.append("\n# rocprofv3 --pmc FETCH_SIZE  /  --pmc WRITE_SIZE  (separate passes) -- python bench.py --no-cpu-baseline --steps 4 --warmup 1")
-out.append("conv_mfma_kernel launches: %d / %d" % (nf, nw))
+out.append("convolution launches: %d / %d" % (nf, nw))
 out.append("FETCH_SIZE avg per launch: %.1f KB raw (gfx950 reports 1/2 of wide coalesced reads; this kernel mixes 16-byte pieces and scalars: between %.1f and %.1f MB)" % (f, f / 1024, 2 * f / 1024))
 out.append("WRITE_SIZE avg per launch: %.1f KB = %.1f MB" % (w, w / 1024))
 out.append("algorithmic bytes per average launch (input once + residual once + output once + weights, batch 8, 64 launches/forward): 147.7 MB")
 out.append("=> measured HBM-side traffic %.0f-%.0f MB per launch vs algorithmic 147.7 MB: no wasted re-reads (halo / weight re-reads are absorbed by L2 and the Infinity Cache);" % ((f + w) / 1024, (2 * f + w) / 1024))
-out.append("   arithmetic intensity %.1f GFLOP / 147.7 MB = %.0f FLOP/B >> ridge 157.3/8 = 19.7 FLOP/B: MFMA-bound, roofline.bound = \"mfma\"." % (dk['algorithmic_gflop_per_launch'], dk['algorithmic_gflop_per_launch'] * 1e3 / 147.7))
-out.append("in-bench HIP-event average launch: %.1f us (%.1f TF/s, frac %.3f)  vs rocprofv3 average %.1f us." % (dk['avg_launch_us'], dk['tflops'], j['roofline']['frac'], tn / nc / 1e3))
+out.append("   arithmetic intensity %.1f GFLOP / 147.7 MB = %.0f FLOP/B >> ridge (2500/6 TF/s)/(8 TB/s) = 52 FLOP/B: MFMA-bound, roofline.bound = \"mfma\"." % (dk['algorithmic_gflop_per_launch'], dk['algorithmic_gflop_per_launch'] * 1e3 / 147.7))
+out.append("in-bench HIP-event average launch: %.1f us (%.1f TF/s algorithmic fp32 = %.3f of the split-bf16 ceiling 416.7 TF/s = %.3f of the fp32-MFMA peak 157.3 TF/s)  vs rocprofv3 average %.1f us." % (dk['avg_launch_us'], dk['tflops'], dk['tflops'] / 416.7, dk['tflops'] / 157.3, tn / nc / 1e3))
 out.append("bench: %.3f images/s, %.2f ms/step; cpu_baseline %.4f images/s on %d threads." % (j['value'], j['ms_per_step'], j.get('cpu_baseline', {}).get('value', float('nan')), j.get('cpu_baseline', {}).get('cores', 0)))
 open('profiles/%s_bench_n1_rocprof_summary.txt' % tag, 'w').write("\n".join(out) + "\n")
 shutil.copy(d + 'bench_kt_kernel_stats.csv', 'profiles/%s_bench_n1_kernel_stats.csv' % tag)
 shutil.copy(d + 'bench_n1.json', 'profiles/%s_bench_n1.json' % tag)
-json.dump({"source": "profiles/%s_bench_n1_rocprof_summary.txt" % tag, "kernel": "conv_mfma_kernel", "launches": nf,
+json.dump({"source": "profiles/%s_bench_n1_rocprof_summary.txt" % tag, "kernel": "conv_bf16x3_pair/stream + conv_mfma (all convolution launches)", "launches": nf,
            "fetch_size_kb_raw": f, "write_size_kb": w, "bytes_per_launch": (2 * f + w) * 1024,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of 16 B/lane reads as 64 B; MI355X guide, HBM section); "
                          "WRITE_SIZE as reported; separate --pmc passes"},

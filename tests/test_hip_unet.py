@@ -96,7 +96,13 @@ def test_p_step_golden(golden, obj):
         for (t, s) in ((1.0, 0.875), (0.5, 0.375), (0.125, 0.0)):
             ddpm.randn = lambda *shape, rng=None, **kw: g["z"].to(DEV)
             y = ddpm.p_step(x_t, torch.full((2,), t), torch.full((2,), s), rng=None, mode=mode, ddim_eta=eta).cpu()
-            assert max_abs(y, g[f"{obj}_{mode}_{eta}_{t}_{s}"]) < 1e-4, (mode, eta, t, s)
+            want = g[f"{obj}_{mode}_{eta}_{t}_{s}"]
+            # t = 1 with the eps objective divides by alpha_t = 5.5e-4: the few pixels that escape the +-1 clamp carry
+            # a ~1800x copy of the fp32-roundoff difference between two U-Net evaluations (see test_sample_golden);
+            # everywhere else, and for all other (t, objective) pairs, 1e-4 holds with a wide margin.
+            tol = 3e-4 if (t == 1.0 and obj == "eps") else 1e-4
+            assert max_abs(y, want) < tol, (mode, eta, t, s)
+            assert torch.quantile((y - want).abs().flatten(), 0.99).item() < 2e-6, (mode, eta, t, s)
 
 
 def _fp64_truth(noise, mode, S, res=GOLDEN_RES):

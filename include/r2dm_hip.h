@@ -93,6 +93,17 @@ int r2dm_posterior_step(const float* x_t, const float* prediction, const float* 
                         float* x_s, int32_t batch, int64_t per_sample, int32_t mode, int32_t objective,
                         float clip, void* stream);
 
+/* -- RePaint completion (models/diffusion/continuous_time.py:169-190 q_step_from_x_0 / q_step, :287-303 the
+ *    known/unknown blend inside repaint()).  coef is (B,2) host-computed scalars.
+ *    blend:  out = mask * (known*alpha + noise*sigma) + (1 - mask) * unknown,  coef = (alpha, sigma) at step s;
+ *            mask has `mask_channels` channels (1 = broadcast over the `channels` planes of a sample).
+ *    q_step: x_t = x_s * a_ts + std * noise,  coef = (alpha_t/alpha_s, sqrt(sigma_t^2 - a_ts^2 sigma_s^2)). */
+int r2dm_repaint_blend(const float* known, const float* noise, const float* unknown, const float* mask,
+                       const float* coef, float* out, int32_t batch, int64_t per_sample, int32_t channels,
+                       int32_t mask_channels, void* stream);
+int r2dm_q_step(const float* x_s, const float* noise, const float* coef, float* x_t, int32_t batch, int64_t per_sample,
+                void* stream);
+
 /* -- sample post-processing: LiDARUtility.denormalize/revert_depth/to_xyz + concat
  *    (utils/lidar.py:49-61,98-120; sample_and_save.py:52-57).  x (B,2,H,W) in [-1,1],
  *    ray_angles (2,H,W) [elevation, azimuth] in rad, out (B,5,H,W) = depth,x,y,z,reflectance. */

@@ -331,6 +331,53 @@ def sample_continuous(
     return torch.stack(out) if return_all else x
 
 
+def q_step_from_x_0(x_0: Tensor, step_t: Tensor, noise: Tensor, log_snr=log_snr_cosine) -> Tensor:
+    """continuous_time.py:169-176: forward process q(z_t | x_0) with the noise passed in."""
+    a, s = alpha_sigma(log_snr(step_t)[:, None, None, None])
+    return x_0 * a + noise * s
+
+
+def q_step(x_s: Tensor, step_t: Tensor, step_s: Tensor, noise: Tensor, log_snr=log_snr_cosine) -> Tensor:
+    """continuous_time.py:178-190: q(z_t | z_s), 0 < s < t < 1."""
+    v4 = lambda t: t[:, None, None, None]
+    a_t, s_t = alpha_sigma(v4(log_snr(step_t)))
+    a_s, s_s = alpha_sigma(v4(log_snr(step_s)))
+    a_ts = a_t / a_s
+    var = s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)
+    return x_s * a_ts + var.sqrt() * noise
+
+
+def repaint_continuous(denoise, known: Tensor, mask: Tensor, num_steps: int, noises: List[Tensor], num_resample_steps: int = 1,
+                       jump_length: int = 1, return_all: bool = False, objective: str = "eps", log_snr=log_snr_cosine):
+    """continuous_time.py:260-317 (RePaint) on an explicit noise tape.  Draw order: initial x_T; per reverse
+    sub-step first the known region's forward noise, then p_step's noise; per forward sub-step one draw."""
+    tape = iter(noises)
+    nxt = lambda: next(tape).to(device=known.device, dtype=known.dtype)
+    B = known.shape[0]
+    x_t = nxt()
+    out = [x_t]
+    steps = torch.linspace(1.0, 0.0, num_steps + 1, device=known.device)[None].repeat_interleave(B, dim=0)
+    x_s = x_t
+    for i in range(num_steps):
+        for j in range(num_resample_steps):
+            t, s = steps[:, [i]], steps[:, [i + 1]]
+            r = t + torch.linspace(0, 1, jump_length + 1, device=known.device)[None] * (s - t)
+            x = x_t
+            for k in range(jump_length):  # t -> s
+                known_s = q_step_from_x_0(known, r[:, k + 1], nxt(), log_snr)
+                unknown_s = p_step_continuous(denoise, x, r[:, k], r[:, k + 1], nxt(), "ddpm", 0.0, objective, log_snr)
+                x = mask * known_s + (1 - mask) * unknown_s
+            x_s = x
+            out.append(x_s)
+            if i == num_steps - 1 or j == num_resample_steps - 1:
+                x_t = x
+                break
+            for k in range(jump_length, 0, -1):  # s -> t
+                x = q_step(x, r[:, k - 1], r[:, k], nxt(), log_snr)
+            x_t = x
+    return torch.stack(out) if return_all else x_s
+
+
 # --------------------------------------------------------------------------------------
 # L3 diffusion (discrete time; secondary path, discrete_time.py)
 # --------------------------------------------------------------------------------------

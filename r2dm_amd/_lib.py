@@ -59,6 +59,8 @@ SIGNATURES = {
     "r2dm_profile_enable": (c_int32, [_P, c_int32]),
     "r2dm_profile_read": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "r2dm_posterior_step": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_float, _P]),
+    "r2dm_repaint_blend": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
+    "r2dm_q_step": (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P]),
     "r2dm_lidar_postprocess": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_float, c_float, _P]),
     "r2dm_conv_packed_elems": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "r2dm_conv2d_ring": (c_int32, [_P, _P, _P, _P, _P, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
@@ -128,6 +130,30 @@ def posterior_step(x_t, pred, noise, coef, mode: int, objective: int, clip: floa
     with torch.cuda.device(x_t.device):
         check(lib().r2dm_posterior_step(ptr(x_t), ptr(pred), ptr(noise), ptr(coef), ptr(out), B,
                                         x_t.numel() // B, mode, objective, float(clip), stream_ptr(x_t.device)))
+    return out
+
+
+def repaint_blend(known, noise, unknown, mask, coef) -> torch.Tensor:
+    """mask * (known*alpha + noise*sigma) + (1 - mask) * unknown; coef (B,2) = (alpha, sigma)."""
+    require_gpu(known, "known")
+    known, noise, unknown, coef = f32c(known), f32c(noise), f32c(unknown), f32c(coef)
+    B, C = known.shape[0], known.shape[1]
+    mask = f32c(mask.to(known.device).expand(B, -1, *known.shape[2:]))
+    out = torch.empty_like(known)
+    with torch.cuda.device(known.device):
+        check(lib().r2dm_repaint_blend(ptr(known), ptr(noise), ptr(unknown), ptr(mask), ptr(coef), ptr(out), B,
+                                       known.numel() // B, C, mask.shape[1], stream_ptr(known.device)))
+    return out
+
+
+def q_step(x_s, noise, coef) -> torch.Tensor:
+    """x_s * a_ts + std * noise; coef (B,2) = (a_ts, std)."""
+    require_gpu(x_s, "x_s")
+    x_s, noise, coef = f32c(x_s), f32c(noise), f32c(coef)
+    out = torch.empty_like(x_s)
+    B = x_s.shape[0]
+    with torch.cuda.device(x_s.device):
+        check(lib().r2dm_q_step(ptr(x_s), ptr(noise), ptr(coef), ptr(out), B, x_s.numel() // B, stream_ptr(x_s.device)))
     return out
 
 

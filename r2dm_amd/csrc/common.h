@@ -143,6 +143,12 @@ struct PosteriorParams {
     float clip;  // < 0: no clamping
 };
 hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s);
+// RePaint (reference continuous_time.py:169-190,287-303): forward re-noising and known/unknown blend
+hipError_t launch_repaint_blend(const float* known, const float* noise, const float* unknown, const float* mask,
+                                const float* coef, float* out, int B, long per_sample, int channels, int mask_c,
+                                hipStream_t s);
+hipError_t launch_q_step(const float* x, const float* noise, const float* coef, float* out, int B, long per_sample,
+                         hipStream_t s);
 
 // (B,2,H,W) in [-1,1] -> (B,5,H,W) [depth, x, y, z, reflectance]  (reference sample_and_save.py:52-57)
 hipError_t launch_lidar_postprocess(const float* x, const float* angles, float* y, int B, int H, int W,

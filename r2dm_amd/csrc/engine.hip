@@ -674,6 +674,21 @@ int r2dm_posterior_step(const float* x_t, const float* pred, const float* noise,
     return 0;
 }
 
+int r2dm_repaint_blend(const float* known, const float* noise, const float* unknown, const float* mask, const float* coef,
+                       float* out, int32_t B, int64_t per_sample, int32_t channels, int32_t mask_channels, void* stream) {
+    if (!known || !noise || !unknown || !mask || !coef || !out) return fail(1, "null argument");
+    HIP_TRY(launch_repaint_blend(known, noise, unknown, mask, coef, out, B, per_sample, channels, mask_channels,
+                                 (hipStream_t)stream));
+    return 0;
+}
+
+int r2dm_q_step(const float* x_s, const float* noise, const float* coef, float* x_t, int32_t B, int64_t per_sample,
+                void* stream) {
+    if (!x_s || !noise || !coef || !x_t) return fail(1, "null argument");
+    HIP_TRY(launch_q_step(x_s, noise, coef, x_t, B, per_sample, (hipStream_t)stream));
+    return 0;
+}
+
 int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t B, int32_t H, int32_t W,
                            float min_depth, float max_depth, void* stream) {
     if (!x || !ang || !out) return fail(1, "null argument");

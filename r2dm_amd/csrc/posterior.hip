@@ -140,4 +140,68 @@ hipError_t launch_lidar_postprocess(const float* x, const float* angles, float* 
     return hipGetLastError();
 }
 
+
+// ---- RePaint pieces (reference continuous_time.py:169-190, 287-303), replayed in the reference's op order -------
+// blend:  out = mask * (known * alpha + noise * sigma) + (1 - mask) * unknown      (q_step_from_x_0 + mask blend)
+// q_step: out = x_s * a_ts + std * noise                                           (forward diffusion s -> t)
+// coef[b] = (alpha, sigma) resp. (a_ts, std): host-computed scalars.  mask has mask_c channels (1 = broadcast).
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void repaint_blend_kernel(const float* __restrict__ known, const float* __restrict__ noise,
+                                                            const float* __restrict__ unknown, const float* __restrict__ mask,
+                                                            const float* __restrict__ coef, float* __restrict__ out,
+                                                            long per_sample, long plane, int mask_c) {
+    const int b = blockIdx.y;
+    const float alpha = coef[2 * b], sigma = coef[2 * b + 1];
+    const long base = b * per_sample;
+    for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
+        const f32x4 k = *reinterpret_cast<const f32x4*>(known + base + i), z = *reinterpret_cast<const f32x4*>(noise + base + i);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(unknown + base + i);
+        const long mi = mask_c == 1 ? b * plane + i % plane : base + i;  // plane % 4 == 0: a quad never straddles planes
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mask + mi);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ks = k[e] * alpha + z[e] * sigma;
+            o[e] = m[e] * ks + (1.0f - m[e]) * u[e];
+        }
+        *reinterpret_cast<f32x4*>(out + base + i) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void q_step_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                     const float* __restrict__ coef, float* __restrict__ out, long per_sample) {
+    const int b = blockIdx.y;
+    const float a = coef[2 * b], sd = coef[2 * b + 1];
+    const long base = b * per_sample;
+    for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i), z = *reinterpret_cast<const f32x4*>(noise + base + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * a + sd * z[e];
+        *reinterpret_cast<f32x4*>(out + base + i) = o;
+    }
+}
+#pragma clang fp contract(fast)
+
+hipError_t launch_repaint_blend(const float* known, const float* noise, const float* unknown, const float* mask,
+                                const float* coef, float* out, int B, long per_sample, int channels, int mask_c,
+                                hipStream_t s) {
+    if (per_sample % 4 || channels <= 0 || per_sample % channels || (per_sample / channels) % 4) return hipErrorInvalidValue;
+    if (mask_c != 1 && mask_c != channels) return hipErrorInvalidValue;
+    long bx = (per_sample / 4 + 255) / 256;
+    if (bx > 256) bx = 256;
+    repaint_blend_kernel<<<dim3((unsigned)bx, B), 256, 0, s>>>(known, noise, unknown, mask, coef, out, per_sample,
+                                                               per_sample / channels, mask_c);
+    return hipGetLastError();
+}
+
+hipError_t launch_q_step(const float* x, const float* noise, const float* coef, float* out, int B, long per_sample,
+                         hipStream_t s) {
+    if (per_sample % 4) return hipErrorInvalidValue;
+    long bx = (per_sample / 4 + 255) / 256;
+    if (bx > 256) bx = 256;
+    q_step_kernel<<<dim3((unsigned)bx, B), 256, 0, s>>>(x, noise, coef, out, per_sample);
+    return hipGetLastError();
+}
+
 }  // namespace r2dm

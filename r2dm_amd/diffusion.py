@@ -307,20 +307,39 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         return torch.stack(out) if return_all else x
 
     # -- forward process pieces used by RePaint (continuous_time.py:169-190) ----------------
+    def _alpha_sigma_rows(self, steps: torch.Tensor) -> torch.Tensor:
+        """(alpha, sigma) per row, float32 on the host, each row evaluated on 1-element tensors (see _coefficients)."""
+        steps = steps.detach().to("cpu", torch.float32).reshape(-1)
+        rows = []
+        for i in range(steps.numel()):
+            a, sg = log_snr_to_alpha_sigma(self._log_snr_1d(steps[i:i + 1]))
+            rows.append(torch.cat([a, sg]))
+        return torch.stack(rows).contiguous()
+
+    def _q_coef_rows(self, step_t: torch.Tensor, step_s: torch.Tensor) -> torch.Tensor:
+        """(alpha_t/alpha_s, sqrt(sigma_t^2 - alpha_ts^2 sigma_s^2)) per row (continuous_time.py:181-189)."""
+        step_t = step_t.detach().to("cpu", torch.float32).reshape(-1)
+        step_s = step_s.detach().to("cpu", torch.float32).reshape(-1)
+        rows = []
+        for i in range(step_t.numel()):
+            a_t, s_t = log_snr_to_alpha_sigma(self._log_snr_1d(step_t[i:i + 1]))
+            a_s, s_s = log_snr_to_alpha_sigma(self._log_snr_1d(step_s[i:i + 1]))
+            a_ts = a_t / a_s
+            var = s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)
+            rows.append(torch.cat([a_ts, var.sqrt()]))
+        return torch.stack(rows).contiguous()
+
     def q_step_from_x_0(self, x_0, step_t, rng=None):
+        """Forward process q(z_t | x_0) (continuous_time.py:169-176); HIP kernel r2dm_q_step."""
         noise = self.randn_like(x_0, rng=rng)
-        alpha, sigma = log_snr_to_alpha_sigma(self.log_snr(step_t.cpu().float()).to(x_0.device))
-        return x_0 * alpha + noise * sigma, noise
+        coef = self._alpha_sigma_rows(step_t).to(x_0.device)  # x_0 * alpha + sigma * noise
+        return _lib.q_step(x_0, noise, coef), noise
 
     def q_step(self, x_s, step_t, step_s, rng=None):
-        lt = self.log_snr(step_t.cpu().float()).to(x_s.device)
-        ls = self.log_snr(step_s.cpu().float()).to(x_s.device)
-        a_t, s_t = log_snr_to_alpha_sigma(lt)
-        a_s, s_s = log_snr_to_alpha_sigma(ls)
-        a_ts = a_t / a_s
+        """q(z_t | z_s), 0 < s < t < 1 (continuous_time.py:178-190); HIP kernel r2dm_q_step."""
+        coef = self._q_coef_rows(step_t, step_s).to(x_s.device)
         var_noise = self.randn_like(x_s, rng=rng)
-        var = s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)
-        return x_s * a_ts + var.sqrt() * var_noise
+        return _lib.q_step(x_s, var_noise, coef)
 
     @torch.inference_mode()
     def repaint(self, known, mask, num_steps: int, num_resample_steps: int = 1, jump_length: int = 1,
@@ -340,9 +359,11 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
                 r = t + torch.linspace(0, 1, jump_length + 1)[None] * (s - t)
                 x = x_t
                 for k in range(jump_length):
-                    known_s, _ = self.q_step_from_x_0(known, r[:, k + 1], rng=rng)
+                    # q_step_from_x_0(known) and the mask blend are one kernel; the draw order (known-region noise,
+                    # then p_step's noise) is the reference's
+                    noise_k = self.randn_like(known, rng=rng)
                     unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng)
-                    x = mask * known_s + (1 - mask) * unknown_s
+                    x = _lib.repaint_blend(known, noise_k, unknown_s, mask, self._alpha_sigma_rows(r[:, k + 1]).to(dev))
                 x_s = x
                 if return_all:
                     out.append(x_s)

@@ -270,6 +270,42 @@ def test_batch32_ddim_runs_and_is_seed_determined():
     assert (a[8:16] - b).pow(2).mean().sqrt() < 5e-5 and max_abs(a[8:16], b) < 5e-2
 
 
+def test_repaint_kernels_replay_reference_ops():
+    """r2dm_repaint_blend / r2dm_q_step vs the reference expressions evaluated op by op by torch on the same GPU
+    (continuous_time.py:175,186-189,296): bit-exact (no FMA contraction in the kernels)."""
+    from r2dm_amd import _lib
+
+    known, noise, unknown = (rnd(70 + i, 3, 2, *GOLDEN_RES).to(DEV) for i in range(3))
+    coef = torch.tensor([[0.3, 0.95], [0.9991, 0.0421], [1.0, 0.0]], device=DEV)
+    a, sg = coef[:, 0].view(3, 1, 1, 1), coef[:, 1].view(3, 1, 1, 1)
+    for mask in ((rnd(73, 3, 1, *GOLDEN_RES) > 0).float().to(DEV), (rnd(74, 3, 2, *GOLDEN_RES) > 0.5).float().to(DEV),
+                 torch.rand(3, 1, *GOLDEN_RES, device=DEV)):
+        want = mask * (known * a + noise * sg) + (1 - mask) * unknown
+        assert torch.equal(_lib.repaint_blend(known, noise, unknown, mask, coef), want)
+    assert torch.equal(_lib.q_step(known, noise, coef), known * a + sg * noise)
+
+
+def test_repaint_golden(golden):
+    """RePaint end to end vs the reference's own run (golden) on the same noise tape; same statistics as
+    test_sample_golden (the reverse sub-steps are p_steps: a few pixels near t = 1 carry amplified roundoff)."""
+    g = golden("repaint")
+    ddpm, _ = build(resolution=GOLDEN_RES)
+    Tape(ddpm, g["noise"])
+    out = ddpm.repaint(g["known"].to(DEV), g["mask"].to(DEV), num_steps=3, num_resample_steps=2, jump_length=2,
+                       progress=False, rng=None, return_all=True).cpu()
+    assert out.shape == g["out"].shape
+    rows = [(max_abs(out[i], g["out"][i]), rms(out[i], g["out"][i]), q99(out[i], g["out"][i])) for i in range(out.shape[0])]
+    print("repaint_golden per output (max, rms, q99 of |hip - reference|):")
+    for r in rows:
+        print("   " + "  ".join(f"{v:.2e}" for v in r))
+    known_px = g["mask"].expand_as(out[-1]) > 0
+    for i, (mx, r, q) in enumerate(rows):
+        assert r < 1e-5 and q < 5e-6 and mx < 1e-3, (i, rows[i])
+    assert rows[-1][0] < 1e-4  # the finished completion: BASELINE's per-pixel bar
+    # where the mask is 1 the last output is the known image re-noised at s = 0, where sigma = 5.5e-4 (logSNR +15)
+    assert max_abs(out[-1][known_px], g["known"].expand_as(out[-1])[known_px]) < 4e-3
+
+
 def test_repaint_keeps_known_region_statistics(small):
     """RePaint (continuous_time.py:260-317) on top of the HIP p_step: with an all-ones mask the result is the
     forward-diffused known image at the last step, i.e. (t -> 0) the known image itself."""

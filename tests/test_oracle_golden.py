@@ -111,6 +111,17 @@ def test_sample_seeded(golden, sd, cfg):
     assert max_abs(out, g["out"]) < 2e-4
 
 
+def test_repaint_noise_tape(golden, sd, cfg):
+    """RePaint (continuous_time.py:260-317): oracle vs the reference's own run on the same noise tape."""
+    g = golden("repaint")
+    net = lambda x, c: O.unet_forward(sd, cfg, x, c)
+    out = O.repaint_continuous(net, g["known"], g["mask"], 3, list(g["noise"]), num_resample_steps=2, jump_length=2,
+                               return_all=True)
+    assert out.shape == g["out"].shape
+    assert max_abs(out, g["out"]) < 2e-4
+    assert max_abs(out[-1], g["out"][-1]) < 2e-5
+
+
 def test_discrete(golden, cfg):
     g = golden("discrete")
     ck = synthetic_ckpt(resolution=GOLDEN_RES, timestep_type="discrete", num_training_steps=1000, noise_schedule="linear")

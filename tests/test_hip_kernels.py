@@ -44,10 +44,32 @@ def test_conv3x3_ring(O, H, cin, cout, h, w):
     x, wt, b = rnd(1, 2, cin, h, w), rnd(2, cout, cin, 3, 3) / math.sqrt(9 * cin), rnd(3, cout)
     ref = O.conv_ring(x.double(), wt.double(), b.double())
     y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
-    # outputs are O(1) (|y| <= ~6); the MFMA accumulates the K = 9*Cin products as ONE fp32 fma chain, whose
-    # roundoff grows like sqrt(K)*2^-24*|partial sums|: ~1.5e-5 worst case over 1e6 outputs at K = 4608
+    # outputs are O(1) (|y| <= ~6); fp32 accumulation of K = 9*Cin products (split-bf16 products or the fp32 fma
+    # chain, two-level for Cin > 128) carries roundoff ~sqrt(576)*2^-24*|partial sums|: a few 1e-6 worst case
     assert max_abs(y, ref) < (2e-5 if cin >= 256 else 1e-5)
     assert max_abs(y, O.conv_ring(x, wt, b)) < 2.5e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,w,B", [(64, 64, 64, 1024, 8), (128, 128, 32, 512, 8), (256, 256, 16, 256, 8),
+                                             (512, 512, 8, 128, 8), (512, 256, 8, 128, 3), (128, 64, 64, 1024, 2)])
+def test_conv3x3_repeatable_at_full_size(H, cin, cout, h, w, B):
+    """The split-bf16 kernels stage weights by LDS-DMA and operand fragments by hand-issued reads, ordered only by
+    hand-counted vmcnt / lgkmcnt waits and barriers: a missing wait shows up as rare, launch-dependent wrong tiles.
+    25 launches at the BASELINE sizes (all CUs busy, several rounds of blocks) must be bit-identical, and agree with
+    an fp64 convolution on a slice."""
+    import torch.nn.functional as F
+
+    x, wt, b = rnd(30, B, cin, h, w).to(DEV), (rnd(31, cout, cin, 3, 3) / math.sqrt(9 * cin)).to(DEV), rnd(32, cout).to(DEV)
+    res = rnd(33, B, cout, h, w).to(DEV)
+    aff = torch.stack([torch.rand(B, cin, device=DEV) + 0.5, torch.randn(B, cin, device=DEV) * 0.3], -1).contiguous()
+    y0 = H.conv2d_ring(x, wt, b, aff=aff, prologue=2, residual=res, scale=0.70710678)
+    for _ in range(24):
+        assert torch.equal(H.conv2d_ring(x, wt, b, aff=aff, prologue=2, residual=res, scale=0.70710678), y0)
+    bs = B - 1  # fp64 check of the last sample
+    xa = F.silu(x[bs:].double() * aff[bs:, :, 0].double()[:, :, None, None] + aff[bs:, :, 1].double()[:, :, None, None])
+    xa = F.pad(F.pad(xa, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1))
+    ref = (res[bs:].double() + F.conv2d(xa, wt.double(), b.double())) * 0.70710678
+    assert max_abs(y0[bs:].cpu(), ref.cpu()) < 2e-5
 
 
 def test_conv3x3_batch_tiling_variants(O, H):

@@ -83,7 +83,8 @@ hipError_t launch_pack_conv(const float* w_oihw, float* dst, int Cout, int Cin, 
                             int cin_pad, hipStream_t s, int algo = ALGO_F32);
 bool conv_bf16x3_supported(int Cin, int Cout, int taps);
 long conv_bf16x3_packed_floats(int Cin, int Cout);
-hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, hipStream_t s);
+int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);
+hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, int co_tile, hipStream_t s);
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s);
 
 struct GNParams {

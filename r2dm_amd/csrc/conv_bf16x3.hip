@@ -85,7 +85,6 @@ constexpr int XPL2 = NG * XR * XS2;      // entries per plane
 constexpr int XBYTES2 = 3 * XPL2 * 16;   // 38592
 constexpr int RING = 4;
 constexpr int WB0 = 2 * XBYTES2;         // [x buffer 0][x buffer 1][weight ring]
-constexpr int LDS2 = WB0 + RING * WBYTES;  // 150912
 }  // namespace x3s
 
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
@@ -107,9 +106,15 @@ __device__ __forceinline__ void dma16s(const void* gbase, unsigned voff, unsigne
 template <int V>
 using ic = std::integral_constant<int, V>;
 
-template <int PRO>
+template <int PRO, int COT>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvParams p) {
     using namespace x3s;
+    // COT = 64: every wave 64 co x 64 px (2 x 2 MFMA tiles).  COT = 32 (launches that would otherwise leave CUs idle):
+    // 32 co x 64 px (1 x 2), half the MFMAs per tap under the same x tile, fragment and transform traffic.
+    constexpr int CO_T = COT, MR = COT / 32, UNITS = 6 * MR * NR, NFR = 3 * (MR + NR);
+    constexpr int WBYTES = 3 * 3 * NG * COT * 16, NPIECE = WBYTES / 1024, PPW = (NPIECE + 3) / 4;  // DMA pieces per wave
+    constexpr int XSL = 24 / UNITS;  // transform slots per unit (144 slots per chunk over taps 1..6)
+    static_assert(COT == 64 || COT == 32, "co tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
 
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     const int H = p.H, W = p.W;
     const int HW = H * W;
     const int nTw = (W + TW - 1) / TW, nTh = (H + TH - 1) / TH;
-    const int nCoT = p.Cout / CO_T;
+    const int nCoT = p.Cout / COT;
     int L = xcd_remap(blockIdx.x, gridDim.x);
     const int cot = L % nCoT;
     L /= nCoT;
@@ -241,13 +246,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     auto xf_write = [&](const unsigned (&qpk)[3][4], unsigned char* buf, int e, int pl) __attribute__((always_inline)) {
         *reinterpret_cast<u32x4*>(buf + dsto[e] + pl * (XPL2 * 16)) = u32x4{qpk[pl][0], qpk[pl][1], qpk[pl][2], qpk[pl][3]};
     };
-    // weights of stage s -> ring slot s % RING: 18 pieces of 1 KiB; every wave issues 5 (the surplus ones repeat piece
-    // 17: same data, same place) so that the vmcnt bookkeeping is the same in all waves
-    unsigned dma_v[5], dma_l[5];  // per-lane byte offset within a stage / LDS base of the piece (ring slot 0)
+    // weights of stage s -> ring slot s % RING: NPIECE pieces of 1 KiB; every wave issues PPW (the surplus ones repeat the
+    // last piece: same data, same place) so that the vmcnt bookkeeping is the same in all waves
+    unsigned dma_v[PPW], dma_l[PPW];  // per-lane byte offset within a stage / LDS base of the piece (ring slot 0)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < PPW; ++i) {
         int j = wave + 4 * i;
-        j = j < 18 ? j : 17;
+        j = j < NPIECE ? j : NPIECE - 1;
         dma_v[i] = (unsigned)(j * 1024 + lane * 16);
         dma_l[i] = lds0 + WB0 + j * 1024;
     }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) dma_piece(s < nstages ? s : nstages - 1, i);
+        for (int i = 0; i < PPW; ++i) dma_piece(s < nstages ? s : nstages - 1, i);
     load_setup(0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) load_piece(i);
@@ -307,15 +312,16 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     auto frag1 = [&](const unsigned (&xb)[NR], unsigned wb, auto KY, auto TX, auto R, u32x4 (&a)[3][MR], u32x4 (&bb)[3][NR])
                      __attribute__((always_inline)) {
         constexpr int ky = decltype(KY)::value, tx = decltype(TX)::value, r = decltype(R)::value;
-        constexpr int pl = r / 4, w = r % 4;
-        if constexpr (w < 2)
+        constexpr int pl = r / (MR + NR), w = r % (MR + NR);
+        if constexpr (r >= NFR) {
+        } else if constexpr (w < MR)
             asm volatile("ds_read_b128 %0, %1 offset:%2"
                          : "=v"(a[pl][w])
                          : "v"(wb), "i"(pl * (3 * NG * CO_T * 16) + tx * (NG * CO_T * 16) + w * 512));
         else
             asm volatile("ds_read_b128 %0, %1 offset:%2"
-                         : "=v"(bb[pl][w - 2])
-                         : "v"(xb[w - 2]), "i"(pl * (XPL2 * 16) + ky * (XS2 * 16) + tx * 16));
+                         : "=v"(bb[pl][w - MR])
+                         : "v"(xb[w - MR]), "i"(pl * (XPL2 * 16) + ky * (XS2 * 16) + tx * 16));
     };
     {
         auto f0 = [&](auto R) __attribute__((always_inline)) { frag1(xcur, lds_w0, ic<0>{}, ic<0>{}, R, fa[0], fb[0]); };
@@ -332,9 +338,9 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         unsigned char* nbuf = smem + ((c + 1) & 1) * XBYTES2;  // x buffer being filled (chunk c+1)
         if (tx == 1) {
             // B_sigma: everybody is past tap (sigma, 0).  Before it: this wave's pieces of stage sigma+1 have landed
-            // (only stage sigma+2's five may still be in flight) and its x-tile writes are done.
+            // (only stage sigma+2's PPW may still be in flight) and its x-tile writes are done.
 #ifndef X3S_NO_BARRIER
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
 #else
@@ -365,18 +371,18 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         __builtin_amdgcn_sched_barrier(0);
         constexpr int PI[6] = {2, 0, 1, 1, 0, 0}, PJ[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            const int q = i / 4, m = (i / 2) & 1, n = i & 1;
+        for (int i = 0; i < UNITS; ++i) {
+            const int q = i / (MR * NR), m = (i / NR) % MR, n = i % NR;
             f32x16& ac = acc[m][n];
             const bf16x8 fra = __builtin_bit_cast(bf16x8, fa[cur][PI[q]][m]), frb = __builtin_bit_cast(bf16x8, fb[cur][PJ[q]][n]);
-            if (t == 0 && i < 4 && (c & bmask) == 0) {  // first product of a block: start from zero
+            if (t == 0 && i < MR * NR && (c & bmask) == 0) {  // first product of a block: start from zero
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra, frb, zero, 0, 0, 0);
             } else {
                 ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra, frb, ac, 0, 0, 0);
             }
             // ---- at most a handful of other instructions in the shadow of this MFMA ----
-            if (i < 12) {  // next tap's fragments (the next chunk's first tap reads the other x buffer)
+            if (i < NFR) {  // next tap's fragments (the next chunk's first tap reads the other x buffer)
                 auto fr = [&](auto R) __attribute__((always_inline)) {
                     if (t < 8)
                         frag1(xcur, wbn, ic<kyn>{}, ic<txn>{}, R, fa[cur ^ 1], fb[cur ^ 1]);
@@ -397,21 +403,24 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
                 if (i == 11) fr(ic<11>{});
             }
 #ifndef X3S_NO_DMA
-            if (tx == 1 && (i & 3) == 1 && i < 20) dma_piece(sdma, i >> 2);  // into the ring slot of stage sigma-1
+            if (tx == 1 && (i & 3) == 1 && i < 4 * PPW) dma_piece(sdma, i >> 2);  // into the ring slot of stage sigma-1
 #endif
 #ifndef X3S_NO_XF
             if (t >= 1 && t <= 6) {  // transform of chunk c+1: 144 slots; stream X pairs 0..7, stream Y pairs 8..15,
-                const int slot = (t - 1) * 24 + i, j = slot / 18, off = slot % 18;  // pair j of a stream in slots 18j..18j+17
-                if (off < 14) {
-                    xf(xv0, xv1, xm0, xm1, xpk, j, off);
-                    xf(yv0, yv1, ym0, ym1, ypk, 8 + j, off);
-                } else if ((j & 3) == 3 && off < 17) {
-                    xf_write(xpk, nbuf, j >> 2, off - 14);
-                    xf_write(ypk, nbuf, (8 + j) >> 2, off - 14);
+#pragma unroll
+                for (int sub = 0; sub < XSL; ++sub) {
+                    const int slot = ((t - 1) * UNITS + i) * XSL + sub, j = slot / 18, off = slot % 18;  // pair j in slots 18j..18j+17
+                    if (off < 14) {
+                        xf(xv0, xv1, xm0, xm1, xpk, j, off);
+                        xf(yv0, yv1, ym0, ym1, ypk, 8 + j, off);
+                    } else if ((j & 3) == 3 && off < 17) {
+                        xf_write(xpk, nbuf, j >> 2, off - 14);
+                        xf_write(ypk, nbuf, (8 + j) >> 2, off - 14);
+                    }
                 }
             }
 #endif
-            if (t == 7 && i >= 12) load_piece(i - 12);  // raw pixels of the chunk after next
+            if (t == 7 && i >= UNITS - 12) load_piece(i - (UNITS - 12));  // raw pixels of the chunk after next
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -805,8 +814,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
 
 // ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane][tap in row][group][co 64][8 ch] bf16 ----
 __global__ void pack_conv_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout,
-                                        int Cin, long total, int sign_shift) {
-    using namespace x3;
+                                        int Cin, long total, int sign_shift, int CO_T) {
+    using x3::CK;
+    using x3::NG;
     const int nchunks = Cin / CK;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i;
@@ -839,6 +849,12 @@ static bool conv_bf16x3_deep(int Cin) { return Cin > 128; }
 // chunks per sign block = 2^shift: shallow kernel flips every 2 chunks; stream kernel: 64-channel blocks (32 for Cin = 64)
 static int conv_bf16x3_sign_shift(int Cin) { return !conv_bf16x3_deep(Cin) ? 1 : Cin >= 128 ? 2 : 1; }
 
+// 64 output channels per block unless that leaves CUs idle (fewer than 256 blocks) and the deep kernel applies
+int conv_bf16x3_co_tile(int Cin, int Cout, long px_batch) {
+    const long nblk = (long)(Cout / 64) * ((px_batch + 255) / 256);
+    return conv_bf16x3_deep(Cin) && nblk < 256 ? 32 : 64;
+}
+
 bool conv_bf16x3_supported(int Cin, int Cout, int taps) {
     // an even number of 32-channel chunk pairs (shallow) / of 64-channel blocks (deep): the sign pattern must balance
     return taps == 9 && Cout % x3::CO_T == 0 && Cin % (32 << conv_bf16x3_sign_shift(Cin)) == 0;
@@ -846,11 +862,12 @@ bool conv_bf16x3_supported(int Cin, int Cout, int taps) {
 
 long conv_bf16x3_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * 3 / 2; }
 
-hipError_t launch_pack_conv_bf16x3(const float* w, float* dst, int Cout, int Cin, hipStream_t s) {
+hipError_t launch_pack_conv_bf16x3(const float* w, float* dst, int Cout, int Cin, int co_tile, hipStream_t s) {
+    if (co_tile != 64 && co_tile != 32) return hipErrorInvalidValue;
     const long total = (long)Cout * Cin * 9 * 3;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total,
-                                                   conv_bf16x3_sign_shift(Cin));
+                                                   conv_bf16x3_sign_shift(Cin), co_tile);
     return hipGetLastError();
 }
 
@@ -871,10 +888,10 @@ static hipError_t launch_x3_pair(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int PRO>
+template <int PRO, int COT>
 static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
-    auto kern = conv_bf16x3_stream_kernel<PRO>;
-    constexpr int lds = x3s::LDS2;
+    auto kern = conv_bf16x3_stream_kernel<PRO, COT>;
+    constexpr int lds = x3s::WB0 + x3s::RING * (3 * 3 * x3::NG * COT * 16);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -882,7 +899,7 @@ static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nTw = (p.W + 63) / 64, nTh = (p.H + 3) / 4, nCoT = p.Cout / x3::CO_T;
+    const int nTw = (p.W + 63) / 64, nTh = (p.H + 3) / 4, nCoT = p.Cout / COT;
     const long nblk = (long)nCoT * nTw * nTh * p.B;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, p);
     return hipGetLastError();
@@ -890,6 +907,7 @@ static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
 
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
     if (!conv_bf16x3_supported(p.Cin, p.Cout, p.taps)) return hipErrorInvalidValue;
+    if (p.co_tile != 64 && !(p.co_tile == 32 && conv_bf16x3_deep(p.Cin))) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % x3::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.H * (long)p.W * 16 >= (1L << 31) || p.W % 4) return hipErrorInvalidValue;
@@ -897,9 +915,9 @@ hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
     ConvParams q = p;
     q.sign_shift = conv_bf16x3_sign_shift(p.Cin);
     switch (p.prologue) {
-        case PRO_NONE: return deep ? launch_x3_stream<PRO_NONE>(q, s) : launch_x3_pair<PRO_NONE>(q, s);
-        case PRO_AFFINE: return deep ? launch_x3_stream<PRO_AFFINE>(q, s) : launch_x3_pair<PRO_AFFINE>(q, s);
-        case PRO_AFFINE_SILU: return deep ? launch_x3_stream<PRO_AFFINE_SILU>(q, s) : launch_x3_pair<PRO_AFFINE_SILU>(q, s);
+        case PRO_NONE: return !deep ? launch_x3_pair<PRO_NONE>(q, s) : p.co_tile == 32 ? launch_x3_stream<PRO_NONE, 32>(q, s) : launch_x3_stream<PRO_NONE, 64>(q, s);
+        case PRO_AFFINE: return !deep ? launch_x3_pair<PRO_AFFINE>(q, s) : p.co_tile == 32 ? launch_x3_stream<PRO_AFFINE, 32>(q, s) : launch_x3_stream<PRO_AFFINE, 64>(q, s);
+        case PRO_AFFINE_SILU: return !deep ? launch_x3_pair<PRO_AFFINE_SILU>(q, s) : p.co_tile == 32 ? launch_x3_stream<PRO_AFFINE_SILU, 32>(q, s) : launch_x3_stream<PRO_AFFINE_SILU, 64>(q, s);
     }
     return hipErrorInvalidValue;
 }

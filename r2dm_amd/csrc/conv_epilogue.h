@@ -99,28 +99,52 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 bq[m * 4 + k8] = q;
             }
         if (lane == 0) {
+            // Slots per (sample, group): two halves of S = stat_slots / 2, each with one slot per (pixel tile, pixel
+            // wave).  A wave whose 32*MR channels contain whole groups writes its sums to half 0 and zeros to half 1; a
+            // wave that holds only half of a 64-channel group (32-channel tiles) writes to the half given by its
+            // position in the group.  Every slot is written exactly once per launch: fixed summation order.
+            constexpr int R8 = MR * 4;                       // 8-channel blocks per wave
+            const int S = p.stat_slots >> 1;
             const int bpg = p.stat_cpg >> 3;                 // 8-channel blocks per group
             const int slot = (th * nTw + tw) * 4 + wave_px;  // 4 slots per pixel tile (unused ones hold zeros)
+            if (bpg <= R8) {
 #pragma unroll
-            for (int g0 = 0; g0 < MR * 4; ++g0) {
-                if (g0 % bpg) continue;
-                double a = 0.0, q = 0.0;
+                for (int g0 = 0; g0 < R8; ++g0) {
+                    if (g0 % bpg) continue;
+                    double a = 0.0, q = 0.0;
 #pragma unroll
-                for (int k8 = 0; k8 < MR * 4; ++k8)
-                    if (k8 >= g0 && k8 < g0 + bpg) {
-                        a += bs[k8];
-                        q += bq[k8];
-                    }
-                const int g = p.stat_goff + (co_u + g0 * 8) / p.stat_cpg;
-                if (co_u + g0 * 8 < p.Cout) {
-                    double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2;
-                    o[0] = a;
-                    o[1] = q;
-                    if (WPX == 2) {  // this variant fills only 2 of the tile's 4 slots
-                        o[4] = 0.0;
-                        o[5] = 0.0;
+                    for (int k8 = 0; k8 < R8; ++k8)
+                        if (k8 >= g0 && k8 < g0 + bpg) {
+                            a += bs[k8];
+                            q += bq[k8];
+                        }
+                    const int g = p.stat_goff + (co_u + g0 * 8) / p.stat_cpg;
+                    if (co_u + g0 * 8 < p.Cout) {
+                        double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2;
+                        o[0] = a;
+                        o[1] = q;
+                        o[2 * S] = 0.0;
+                        o[2 * S + 1] = 0.0;
+                        if (WPX == 2) {  // this variant fills only 2 of the tile's 4 slots
+                            o[4] = 0.0;
+                            o[5] = 0.0;
+                            o[2 * S + 4] = 0.0;
+                            o[2 * S + 5] = 0.0;
+                        }
                     }
                 }
+            } else {  // the wave's channels are one half of a group (bpg == 2 * R8)
+                double a = 0.0, q = 0.0;
+#pragma unroll
+                for (int k8 = 0; k8 < R8; ++k8) {
+                    a += bs[k8];
+                    q += bq[k8];
+                }
+                const int g = p.stat_goff + co_u / p.stat_cpg;
+                const int half = (co_u % p.stat_cpg) / (R8 * 8);
+                double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + half * S + slot) * 2;
+                o[0] = a;
+                o[1] = q;
             }
         }
     }

@@ -450,11 +450,16 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
                 const int g = p.stat_goff + (co_u + g0 * 8) / p.stat_cpg;
                 if (co_u + g0 * 8 < p.Cout) {
                     double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2;
+                    const int S2 = p.stat_slots & ~1;  // second half of the slots (see conv_epilogue.h): zeros
                     o[0] = a;
                     o[1] = q;
+                    o[S2] = 0.0;
+                    o[S2 + 1] = 0.0;
                     if (WPX == 2) {  // this variant fills only 2 of the tile's 4 slots
                         o[4] = 0.0;
                         o[5] = 0.0;
+                        o[S2 + 4] = 0.0;
+                        o[S2 + 5] = 0.0;
                     }
                 }
             }
@@ -491,7 +496,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
 
 hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int co_tile, int cin_pad,
                             hipStream_t s, int algo) {
-    if (algo == ALGO_BF16X3) return launch_pack_conv_bf16x3(w, dst, Cout, Cin, s);
+    if (algo == ALGO_BF16X3) return launch_pack_conv_bf16x3(w, dst, Cout, Cin, co_tile, s);
     const int nT = (Cout + co_tile - 1) / co_tile;
     const long total = (long)nT * cin_pad * taps * co_tile;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -531,7 +536,7 @@ int conv_pick_co_tile(int Cout, int taps, long px_batch) {
     return 64;
 }
 
-int conv_stat_slots(int H, int W) { return ((H + 3) / 4) * ((W + 63) / 64) * 4; }
+int conv_stat_slots(int H, int W) { return ((H + 3) / 4) * ((W + 63) / 64) * 4 * 2; }  // two halves: conv_epilogue.h
 
 int conv_cin_pad(int Cin, int taps, int co_tile) {
     const int ck = taps == 9 ? (co_tile == 128 ? kCK3_128 : co_tile == 64 ? kCK3_64_DEEP : kCK3_32) : kCK1;

@@ -116,7 +116,7 @@ struct r2dm_handle {
         L.cout = cout;
         L.taps = ksize * ksize;
         L.algo = conv_pick_algo(cin, cout, L.taps);
-        L.co_tile = L.algo == ALGO_BF16X3 ? 64 : conv_pick_co_tile(cout, L.taps, px_batch);
+        L.co_tile = L.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, px_batch) : conv_pick_co_tile(cout, L.taps, px_batch);
         L.cin_pad = L.algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
         L.w = take(L.packed_elems());
         slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
@@ -373,7 +373,7 @@ struct Ctx {
             p.co_tile = L.co_tile;
             p.algo = L.algo;
             p.prologue = pro;
-            if (sink && *sink && L.co_tile >= 64) {
+            if (sink && *sink && (L.co_tile >= 64 || L.algo == ALGO_BF16X3)) {
                 p.stat = sink->p;
                 p.stat_G = h->cfg.gn_num_groups;
                 p.stat_goff = goff;
@@ -725,7 +725,7 @@ int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_
 int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t B, int32_t H, int32_t W) {
     const int taps = ksize * ksize;
     const int algo = conv_pick_algo(cin, cout, taps);
-    const int ct = algo == ALGO_BF16X3 ? 64 : conv_pick_co_tile(cout, taps, (long)B * H * W);
+    const int ct = algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, taps, (long)B * H * W);
     return (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, taps, ct));
 }
 
@@ -738,7 +738,7 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     ConvParams p;
     p.taps = ksize * ksize;
     p.algo = conv_pick_algo(cin, cout, p.taps);
-    p.co_tile = p.algo == ALGO_BF16X3 ? 64 : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    p.co_tile = p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
     p.CinPad = p.algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
     HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
     p.x = Src{x, nullptr, cin, 0, (long)cin * H * W, 0};

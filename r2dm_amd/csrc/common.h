@@ -79,8 +79,9 @@ long conv_packed_floats(int algo, int Cin, int Cout, int taps, int co_tile, int 
 int conv_pick_co_tile(int Cout, int taps, long pixels_times_batch);
 int conv_cin_pad(int Cin, int taps, int co_tile);
 hipError_t launch_conv(const ConvParams& p, hipStream_t s);
+// src_cin / src_off: pack input channels [src_off, src_off + Cin) of a (Cout, src_cin, k, k) source (0 = whole tensor)
 hipError_t launch_pack_conv(const float* w_oihw, float* dst, int Cout, int Cin, int taps, int co_tile,
-                            int cin_pad, hipStream_t s, int algo = ALGO_F32);
+                            int cin_pad, hipStream_t s, int algo = ALGO_F32, int src_cin = 0, int src_off = 0);
 bool conv_bf16x3_supported(int Cin, int Cout, int taps);
 long conv_bf16x3_packed_floats(int Cin, int Cout);
 int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);

@@ -151,13 +151,15 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
             for (int j = 0; j < C::NQT; ++j) {
                 const int cl = (clbits >> (4 * j)) & 15, ci = ci0 + cl;
                 const bool ok = ((okbits >> j) & 1) && ci < p.Cin;
-                const float* pl = ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW;
+                const int cc = ci < p.Cin ? ci : p.Cin - 1;  // padded channels: load (and discard) from a plane that exists
+                const float* pl = cc < c0 ? xb0 + (long)cc * HW : xb1 + (long)(cc - c0) * HW;
                 xq[j] = *reinterpret_cast<const f32x4*>(pl + (ok ? qoff[j] - cl * HW : 0));
             }
             if (C::NHT) {
                 const int cl = clbits >> 28, ci = ci0 + cl;
                 const bool ok = ((okbits >> 8) & 1) && ci < p.Cin;
-                const float* pl = ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW;
+                const int cc = ci < p.Cin ? ci : p.Cin - 1;
+                const float* pl = cc < c0 ? xb0 + (long)cc * HW : xb1 + (long)(cc - c0) * HW;
                 xh = pl[ok ? hoff - cl * HW : 0];
             }
         }
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
 
 // ---- weight packing: OIHW (or (Cout,Cin) for Linear) -> [nCoT][CinPad][taps][CO_T], zero padded ----
 __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin,
-                                 int taps, int co_tile, int cin_pad, long total) {
+                                 int taps, int co_tile, int cin_pad, long total, int src_cin, int src_off) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int col = i % co_tile;
         long r = i / co_tile;
@@ -490,17 +492,18 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
         const int ci = r % cin_pad;
         const int t = r / cin_pad;
         const int co = t * co_tile + col;
-        dst[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+        dst[i] = (co < Cout && ci < Cin) ? w[((long)co * src_cin + src_off + ci) * taps + tap] : 0.f;  // input-channel slice
     }
 }
 
 hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int co_tile, int cin_pad,
-                            hipStream_t s, int algo) {
-    if (algo == ALGO_BF16X3) return launch_pack_conv_bf16x3(w, dst, Cout, Cin, co_tile, s);
+                            hipStream_t s, int algo, int src_cin, int src_off) {
+    if (src_cin <= 0) src_cin = Cin;
+    if (algo == ALGO_BF16X3) return src_cin == Cin ? launch_pack_conv_bf16x3(w, dst, Cout, Cin, co_tile, s) : hipErrorInvalidValue;
     const int nT = (Cout + co_tile - 1) / co_tile;
     const long total = (long)nT * cin_pad * taps * co_tile;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    pack_conv_kernel<<<blocks, 256, 0, s>>>(w, dst, Cout, Cin, taps, co_tile, cin_pad, total);
+    pack_conv_kernel<<<blocks, 256, 0, s>>>(w, dst, Cout, Cin, taps, co_tile, cin_pad, total, src_cin, src_off);
     return hipGetLastError();
 }
 

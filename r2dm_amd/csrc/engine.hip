@@ -44,6 +44,7 @@ inline size_t align_up(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a
 // ---- plan -----------------------------------------------------------------------------------
 struct ConvLayer {
     int cin = 0, cout = 0, taps = 0, co_tile = 0, cin_pad = 0, algo = 0;
+    int src_cin = 0, src_off = 0;  // packs input channels [src_off, src_off + cin) of a (cout, src_cin, k, k) tensor
     size_t w = 0, b = 0;  // blob offsets in floats
     size_t packed_elems() const { return (size_t)conv_packed_floats(algo, cin, cout, taps, co_tile, cin_pad); }
 };
@@ -90,6 +91,11 @@ struct r2dm_handle {
     float* blob = nullptr;
     Stage stages[8];
     ConvLayer in_conv, out_conv;
+    // in_conv over cat([x, cenc]) = conv(x, W[:, :C]) + [conv(cenc, W[:, C:]) + bias]: the bracket is constant over steps
+    // and batch (efficient_unet.py:278-281), computed once per weight load into `cmap` (Cout, H, W)
+    ConvLayer in_conv_c;
+    size_t cmap = 0, zero_bias = 0;
+    bool cmap_ready = false;
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
     int ada_rows = 0;
     std::map<int, size_t> ws_cache;
@@ -110,6 +116,21 @@ struct r2dm_handle {
         return off;
     }
     void raw_at(const std::string& key, int64_t numel, size_t off) { slots.push_back({key, numel, SLOT_RAW, off, {}}); }
+    // the weight-only half of a convolution whose source tensor is shared with another layer (no bias slot)
+    ConvLayer conv_slice(const std::string& wkey, int src_cin, int src_off, int cin, int cout, int ksize, long px_batch) {
+        ConvLayer L;
+        L.cin = cin;
+        L.cout = cout;
+        L.taps = ksize * ksize;
+        L.algo = ALGO_F32;
+        L.co_tile = conv_pick_co_tile(cout, L.taps, px_batch);
+        L.cin_pad = conv_cin_pad(cin, L.taps, L.co_tile);
+        L.src_cin = src_cin;
+        L.src_off = src_off;
+        L.w = take(L.packed_elems());
+        slots.push_back({wkey, (int64_t)cout * src_cin * L.taps, SLOT_CONV, L.w, L});
+        return L;
+    }
     ConvLayer conv(const std::string& wkey, const std::string& bkey, int cin, int cout, int ksize, long px_batch) {
         ConvLayer L;
         L.cin = cin;
@@ -140,7 +161,17 @@ void build_plan(r2dm_handle* h) {
     h->b1 = h->raw("time_embedding.1.bias", T);
     h->w2 = h->raw("time_embedding.3.weight", (int64_t)T * T);
     h->b2 = h->raw("time_embedding.3.bias", T);
-    h->in_conv = h->conv("in_conv.weight", "in_conv.bias", c.in_channels + c.coord_channels, C0, 3, px1);
+    if (c.coord_channels > 0) {
+        const int cin = c.in_channels + c.coord_channels;
+        h->in_conv = h->conv_slice("in_conv.weight", cin, 0, c.in_channels, C0, 3, px1);
+        h->in_conv_c = h->conv_slice("in_conv.weight", cin, c.in_channels, c.coord_channels, C0, 3, (long)c.height * c.width);
+        h->in_conv_c.b = h->raw("in_conv.bias", C0);
+        h->zero_bias = h->take(C0);
+        h->in_conv.b = h->zero_bias;
+        h->cmap = h->take((size_t)C0 * c.height * c.width);
+    } else {
+        h->in_conv = h->conv("in_conv.weight", "in_conv.bias", c.in_channels, C0, 3, px1);
+    }
 
     struct Def { const char* name; int cin, cout, n, level; bool down, up, attn; };
     const Def defs[8] = {
@@ -346,7 +377,8 @@ struct Ctx {
     }
 
     Tensor conv(const ConvLayer& L, const Src& x, int H, int W, int pro, const float2* aff, const Tensor* res,
-                size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0) {
+                size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0,
+                bool res_broadcast = false) {
         Tensor y;
         y.C = L.cout;
         y.H = H;
@@ -359,7 +391,7 @@ struct Ctx {
             p.bias = blob(L.b);
             p.aff = aff;
             p.res = res ? res->p : nullptr;
-            p.res_bs = res ? res->bs() : 0;
+            p.res_bs = res && !res_broadcast ? res->bs() : 0;
             p.scale = has_scale ? blob(scale_off) : nullptr;
             p.y = y.p;
             p.y_bs = y.bs();
@@ -517,9 +549,39 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
         k.note(launch_time_embedding(e, st), "time_embedding");
         k.note(launch_ada_proj(act, k.blob(h->ada_w), k.blob(h->ada_b), proj, B, T, h->ada_rows, st), "ada_proj");
     }
-    // input = cat([x, cenc]) without materialising it (efficient_unet.py:278-281)
-    Src in{x, c.coord_channels ? k.blob(h->cenc) : nullptr, c.in_channels, c.coord_channels,
-           (long)c.in_channels * H * W, 0};
+    // input = cat([x, cenc]) (efficient_unet.py:278-281), never materialised: the constant cenc half of in_conv is the
+    // per-pixel bias map `cmap`, the per-step convolution runs over the in_channels data channels only
+    Src in{x, nullptr, c.in_channels, 0, (long)c.in_channels * H * W, 0};
+    if (c.coord_channels && !h->cmap_ready && !k.dry()) {
+        ConvParams q;
+        q.x = Src{k.blob(h->cenc), nullptr, c.coord_channels, 0, 0, 0};
+        q.w = k.blob(h->in_conv_c.w);
+        q.bias = k.blob(h->in_conv_c.b);
+        q.aff = nullptr;
+        q.res = nullptr;
+        q.res_bs = 0;
+        q.scale = nullptr;
+        q.y = h->blob + h->cmap;
+        q.y_bs = 0;
+        q.B = 1;
+        q.H = H;
+        q.W = W;
+        q.Cin = h->in_conv_c.cin;
+        q.CinPad = h->in_conv_c.cin_pad;
+        q.Cout = h->in_conv_c.cout;
+        q.taps = 9;
+        q.co_tile = h->in_conv_c.co_tile;
+        q.algo = ALGO_F32;
+        q.prologue = PRO_NONE;
+        k.note(hipMemsetAsync(h->blob + h->zero_bias, 0, h->in_conv.cout * sizeof(float), st), "zero bias");
+        k.note(launch_conv(q, st), "in_conv constant map");
+        h->cmap_ready = true;
+    }
+    Tensor cmap_t;
+    cmap_t.p = h->blob + h->cmap;
+    cmap_t.C = h->in_conv.cout;
+    cmap_t.H = H;
+    cmap_t.W = W;
     const int G = c.gn_num_groups;
     const Stage* S = h->stages;
     // GroupNorm sinks that outlive a stage: the first norm of d_block1 (input = in_conv output) and the first norm of
@@ -530,7 +592,7 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     Ctx::Sink s_u2 = k.make_sink(S[6].cin, H / 2, W / 2);
     Ctx::Sink s_u3 = k.make_sink(S[5].cin, H / 4, W / 4);
     Ctx::Sink s_u4 = k.make_sink(S[4].cin, H / 8, W / 8);
-    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, &s_d1, 0);
+    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, c.coord_channels ? &cmap_t : nullptr, 0, false, nullptr, &s_d1, 0, /*res_broadcast=*/true);
     Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2);
     k.drop(h0);
     k.drop_sink(s_d1);
@@ -624,6 +686,7 @@ int r2dm_bind_blob(r2dm_handle* h, void* blob, size_t bytes) {
     if (bytes < r2dm_blob_bytes(h)) return fail(1, "blob too small: %zu < %zu", bytes, r2dm_blob_bytes(h));
     if ((uintptr_t)blob & (kAlign - 1)) return fail(1, "blob must be %zu-byte aligned", kAlign);
     h->blob = (float*)blob;
+    h->cmap_ready = false;
     return 0;
 }
 
@@ -638,8 +701,9 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
         HIP_TRY(hipMemcpyAsync(h->blob + s.off, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         HIP_TRY(launch_pack_conv(src, h->blob + s.off, s.conv.cout, s.conv.cin, s.conv.taps, s.conv.co_tile,
-                                 s.conv.cin_pad, st, s.conv.algo));
+                                 s.conv.cin_pad, st, s.conv.algo, s.conv.src_cin, s.conv.src_off));
     }
+    h->cmap_ready = false;  // (any reload: cheap to recompute)
     return 0;
 }
 

@@ -425,7 +425,9 @@ struct Ctx {
                     e0 = h->prof_ev[h->prof_used];
                     e1 = h->prof_ev[h->prof_used + 1];
                     h->prof_used += 2;
-                    h->prof_flop += 2.0 * B * (double)L.cout * L.cin * L.taps * H * W;
+                    // ALGORITHMIC flops of the reference's convolution (in_conv: all 34 input channels, although the
+                    // constant Fourier half is folded into a bias map here)
+                    h->prof_flop += 2.0 * B * (double)L.cout * (L.src_cin ? L.src_cin : L.cin) * L.taps * H * W;
                     (void)hipEventRecord(e0, st);
                 }
             }

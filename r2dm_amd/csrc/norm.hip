@@ -73,8 +73,9 @@ __global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(Src x, int cpg, 
     }
 }
 
-// grid = (G, B), one wave: combine the splits in index order, then emit (a, d) for the group's channels.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restrict__ partial, int splits, int C,
+// grid = (G, B), 256 threads: combine the splits in a fixed order (thread -> slots, lanes -> wave, waves in index order),
+// then emit (a, d) for the group's channels.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, int splits, int C,
                                                          int cpg, long hw, float eps,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
@@ -83,12 +84,20 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
     const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x;
     const double* p = partial + ((long)b * G + g) * splits * 2;
     double sum = 0.0, sq = 0.0;
-    for (int s = threadIdx.x; s < splits; s += 64) {  // fixed lane -> slot assignment: deterministic
+    for (int s = threadIdx.x; s < splits; s += 256) {  // fixed thread -> slot assignment: deterministic
         sum += p[2 * s];
         sq += p[2 * s + 1];
     }
+    __shared__ double red[2][4];
     sum = wave_sum(sum);
     sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sum;
+        red[1][threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double n = (double)cpg * (double)hw;
     const double mean_d = sum / n;
     double var_d = sq / n - mean_d * mean_d;
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
         stats[((long)b * G + g) * 2 + 0] = mean;
         stats[((long)b * G + g) * 2 + 1] = rstd;
     }
-    for (int i = threadIdx.x; i < cpg; i += 64) {
+    for (int i = threadIdx.x; i < cpg; i += 256) {
         const int c = g * cpg + i;
         float w, sh;
         if (ada) {
@@ -132,14 +141,14 @@ hipError_t launch_group_norm(const GNParams& p, hipStream_t st) {
     const long hw = (long)p.H * p.W;
     const int splits = gn_splits(p.B, p.groups, cpg * hw);
     gn_partial_kernel<<<dim3(splits, p.groups, p.B), kGnThreads, 0, st>>>(p.x, cpg, hw, splits, p.partial);
-    gn_finalize_kernel<<<dim3(p.groups, p.B), 64, 0, st>>>(p.partial, splits, C, cpg, hw, p.eps, p.gamma, p.beta,
+    gn_finalize_kernel<<<dim3(p.groups, p.B), 256, 0, st>>>(p.partial, splits, C, cpg, hw, p.eps, p.gamma, p.beta,
                                                             p.ada, p.ada_stride, p.aff, p.stats);
     return hipGetLastError();
 }
 
 hipError_t launch_group_norm_finalize(const GNParams& p, int C, int splits, hipStream_t st) {
     if (C % p.groups) return hipErrorInvalidValue;
-    gn_finalize_kernel<<<dim3(p.groups, p.B), 64, 0, st>>>(p.partial, splits, C, C / p.groups, (long)p.H * p.W, p.eps, p.gamma,
+    gn_finalize_kernel<<<dim3(p.groups, p.B), 256, 0, st>>>(p.partial, splits, C, C / p.groups, (long)p.H * p.W, p.eps, p.gamma,
                                                             p.beta, p.ada, p.ada_stride, p.aff, p.stats);
     return hipGetLastError();
 }

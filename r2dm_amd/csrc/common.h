@@ -50,7 +50,8 @@ enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2 };
 // ALGO_F32: fp32-input MFMA (conv_mfma.hip).  ALGO_BF16X3: fp32 operands split exactly into three bf16 pieces, six
 // bf16 MFMA products per fp32 product, fp32 accumulation (conv_bf16x3.hip) -- same accuracy class, 2.7x fewer
 // matrix-pipe cycles; needs 3x3, Cin % 16 == 0, Cout % 64 == 0.
-enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1 };
+// ALGO_DIRECT: Cout <= 4 (out_conv): HBM-bound, direct fp32 FMA convolution, weights kept OIHW (conv_direct.hip).
+enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1, ALGO_DIRECT = 2 };
 
 struct ConvParams {
     Src x;               // input activation
@@ -83,6 +84,8 @@ hipError_t launch_conv(const ConvParams& p, hipStream_t s);
 hipError_t launch_pack_conv(const float* w_oihw, float* dst, int Cout, int Cin, int taps, int co_tile,
                             int cin_pad, hipStream_t s, int algo = ALGO_F32, int src_cin = 0, int src_off = 0);
 bool conv_bf16x3_supported(int Cin, int Cout, int taps);
+bool conv_direct_supported(int Cout, int taps);
+hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s);
 long conv_bf16x3_packed_floats(int Cin, int Cout);
 int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);
 hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, int co_tile, hipStream_t s);

@@ -499,6 +499,9 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
 hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int co_tile, int cin_pad,
                             hipStream_t s, int algo, int src_cin, int src_off) {
     if (src_cin <= 0) src_cin = Cin;
+    if (algo == ALGO_DIRECT)
+        return src_cin == Cin ? hipMemcpyAsync(dst, w, (size_t)Cout * Cin * taps * sizeof(float), hipMemcpyDeviceToDevice, s)
+                              : hipErrorInvalidValue;
     if (algo == ALGO_BF16X3) return src_cin == Cin ? launch_pack_conv_bf16x3(w, dst, Cout, Cin, co_tile, s) : hipErrorInvalidValue;
     const int nT = (Cout + co_tile - 1) / co_tile;
     const long total = (long)nT * cin_pad * taps * co_tile;
@@ -521,11 +524,14 @@ int conv_pick_algo(int Cin, int Cout, int taps) {
         const char* e = getenv("R2DM_CONV_ALGO");
         return e && e[0] == 'f';
     }();
-    return !force_f32 && conv_bf16x3_supported(Cin, Cout, taps) ? ALGO_BF16X3 : ALGO_F32;
+    if (force_f32) return ALGO_F32;
+    if (conv_direct_supported(Cout, taps) && Cin <= 1024) return ALGO_DIRECT;
+    return conv_bf16x3_supported(Cin, Cout, taps) ? ALGO_BF16X3 : ALGO_F32;
 }
 
 long conv_packed_floats(int algo, int Cin, int Cout, int taps, int co_tile, int cin_pad) {
     if (algo == ALGO_BF16X3) return conv_bf16x3_packed_floats(Cin, Cout);
+    if (algo == ALGO_DIRECT) return (long)Cout * Cin * taps;  // OIHW as is
     return (long)((Cout + co_tile - 1) / co_tile) * cin_pad * taps * co_tile;
 }
 
@@ -576,6 +582,7 @@ static hipError_t launch_pro(const ConvParams& p, hipStream_t s) {
 
 hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.algo == ALGO_BF16X3) return launch_conv_bf16x3(p, s);
+    if (p.algo == ALGO_DIRECT) return launch_conv_direct(p, s);
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.CinPad != conv_cin_pad(p.Cin, p.taps, p.co_tile)) return hipErrorInvalidValue;
     if (p.H * (long)p.W * 16 >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit element offsets within a chunk

@@ -138,7 +138,7 @@ struct r2dm_handle {
         L.taps = ksize * ksize;
         L.algo = conv_pick_algo(cin, cout, L.taps);
         L.co_tile = L.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, px_batch) : conv_pick_co_tile(cout, L.taps, px_batch);
-        L.cin_pad = L.algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
+        L.cin_pad = L.algo != ALGO_F32 ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
         L.w = take(L.packed_elems());
         slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
         L.b = raw(bkey, cout);
@@ -790,9 +790,10 @@ int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_
 // ---- single-kernel entry points (unit parity tests) ---------------------------------------------
 int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t B, int32_t H, int32_t W) {
     const int taps = ksize * ksize;
-    const int algo = conv_pick_algo(cin, cout, taps);
+    int algo = conv_pick_algo(cin, cout, taps);
+    if (algo == ALGO_DIRECT) algo = ALGO_F32;  // scratch sized for the larger (fp32-MFMA) packing: either may be chosen
     const int ct = algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, taps, (long)B * H * W);
-    return (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, taps, ct));
+    return (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo != ALGO_F32 ? cin : conv_cin_pad(cin, taps, ct));
 }
 
 int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w_packed, const float* aff,
@@ -804,8 +805,9 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     ConvParams p;
     p.taps = ksize * ksize;
     p.algo = conv_pick_algo(cin, cout, p.taps);
+    if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale)) p.algo = ALGO_F32;  // plain convolutions only
     p.co_tile = p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
-    p.CinPad = p.algo == ALGO_BF16X3 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
+    p.CinPad = p.algo != ALGO_F32 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
     HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
     p.x = Src{x, nullptr, cin, 0, (long)cin * H * W, 0};
     p.w = w_packed;

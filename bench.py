@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x2"], default="fp32",
+                    help="fp32 (default): the parity mode BASELINE.json's metric is quoted on.  bf16x2: the optional "
+                         "reduced-precision sampling mode (SURVEY.md section 8 (f).3) -- NOT the headline number")
     args = ap.parse_args()
 
     import r2dm_amd
@@ -99,7 +102,8 @@ def main():
 
     B = args.batch
     ck = synthetic.synthetic_checkpoint(seed=0, resolution=RES)
-    ddpm, lidar, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=B)
+    ddpm, lidar, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=B, precision=args.precision)
+    peak_split = PEAK_BF16 / (6 if args.precision == "fp32" else 3)
     ddpm.to(dev)
     broadcast_packed_weights(ddpm.model, dev, src=0)  # rank 0 packs, everyone else adopts the blob
     seeds = shard_seeds(list(range(B * world)), rank, world)
@@ -153,17 +157,20 @@ def main():
         line = {
             "metric": "range-images/sec (64x1024, 256-step DDPM)", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3x3 conv operands split exactly into 3 bf16 pieces on the bf16 matrix pipe, fp32 accumulate; everything else plain fp32)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f32 (3x3 conv operands split exactly into 3 bf16 pieces on the bf16 matrix pipe, fp32 accumulate; everything else plain fp32)"
+                      if args.precision == "fp32" else
+                      "REDUCED PRECISION bf16x2 (3x3 conv operands = 2 bf16 pieces, 16 mantissa bits; optional mode, not the parity mode)"),
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 64x1024x2 range/reflectance, 256-step DDPM, batch 8 per GPU; "
                                    "timed = one sample() call of --steps reverse steps, value scaled to 256 steps",
                        "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
                        "sampler_steps": SAMPLER_STEPS, "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
-            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_SPLIT / 1e12, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] * 1e12 / PEAK_SPLIT, "traffic": pmc_traffic(),
-                         "peak_definition": "dense bf16 MFMA peak 2500 TF/s / 6 bf16 products per algorithmic fp32 product",
+            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": peak_split / 1e12, "unit": "TFLOP/s",
+                         "frac": conv["tflops"] * 1e12 / peak_split, "traffic": pmc_traffic(),
+                         "peak_definition": "dense bf16 MFMA peak 2500 TF/s / %d bf16 products per algorithmic fp32 product" % (6 if args.precision == "fp32" else 3),
                          "fp32_mfma_peak": PEAK_FP32 / 1e12, "frac_of_fp32_mfma_peak": conv["tflops"] * 1e12 / PEAK_FP32,
                          "dominant_kernel": conv,
-                         "whole_step": {"achieved": step_flops / 1e12, "frac": step_flops / PEAK_SPLIT,
+                         "whole_step": {"achieved": step_flops / 1e12, "frac": step_flops / peak_split,
                                         "frac_of_fp32_mfma_peak": step_flops / PEAK_FP32,
                                         "note": "234.52 GFLOP/image-step x batch / HIP-event time of the timed sample() call"},
                          "note": "achieved = sum of algorithmic conv FLOPs / sum of conv kernel time (HIP events on the sampling "

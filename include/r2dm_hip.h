@@ -77,6 +77,13 @@ size_t r2dm_workspace_bytes(const r2dm_handle* h, int32_t batch);
 int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t batch,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* -- reduced-precision sampling (the counterpart of the reference's mixed-precision bulk mode, sample_and_save.py:70,
+ *    utils/option.py:49).  The 3x3 convolutions split every fp32 operand into bf16 pieces: 3 pieces / 6 products
+ *    reproduce the fp32 product to 2^-23 (default: fp32-class error, the parity mode); 2 pieces / 3 products keep 16
+ *    mantissa bits per operand (~2^-16 relative error per product, still 30x tighter than fp16 autocast) at half the
+ *    matrix-pipe work.  Everything else stays fp32.  h == NULL sets the mode of the single-kernel entry r2dm_conv2d_ring. */
+int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
+
 /* -- measurement aid (bench.py): when enabled, every launch of the dominant kernel class -- the MFMA
  *    convolution, conv_mfma_kernel, 60 launches per forward -- is bracketed by hipEvents recorded on the
  *    caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed

@@ -56,6 +56,7 @@ SIGNATURES = {
     "r2dm_load_tensor": (c_int32, [_P, c_int64, _P, c_int64, _P]),
     "r2dm_workspace_bytes": (c_size_t, [_P, c_int32]),
     "r2dm_unet_forward": (c_int32, [_P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "r2dm_set_conv_pieces": (c_int32, [_P, c_int32]),
     "r2dm_profile_enable": (c_int32, [_P, c_int32]),
     "r2dm_profile_read": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "r2dm_posterior_step": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_float, _P]),

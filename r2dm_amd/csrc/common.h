@@ -68,6 +68,8 @@ struct ConvParams {
     int co_tile;         // 32 / 64 / 128 (must match the packing)
     int prologue;        // Prologue
     int algo = ALGO_F32; // ConvAlgo (must match the packing of `w`)
+    int pieces = 3;      // ALGO_BF16X3: bf16 pieces per fp32 operand; 3 = exact split, 6 products (fp32-class error);
+                         // 2 = reduced-precision mode, 3 products, ~2^-16 relative error
     int sign_shift = 0;  // ALGO_BF16X3 shallow kernel: accumulator sign flips every 2^sign_shift chunks (set by the launcher)
     // optional fused GroupNorm statistics of the OUTPUT (for the GroupNorm that consumes it): per (sample, group)
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]

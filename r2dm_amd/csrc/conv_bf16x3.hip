@@ -106,12 +106,17 @@ __device__ __forceinline__ void dma16s(const void* gbase, unsigned voff, unsigne
 template <int V>
 using ic = std::integral_constant<int, V>;
 
-template <int PRO, int COT>
+template <int PRO, int COT, int NPC>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvParams p) {
     using namespace x3s;
     // COT = 64: every wave 64 co x 64 px (2 x 2 MFMA tiles).  COT = 32 (launches that would otherwise leave CUs idle):
     // 32 co x 64 px (1 x 2), half the MFMAs per tap under the same x tile, fragment and transform traffic.
-    constexpr int CO_T = COT, MR = COT / 32, UNITS = 6 * MR * NR, NFR = 3 * (MR + NR);
+    // NPC = 3: exact three-piece split, six products (fp32-class error).  NPC = 2 (reduced-precision mode, SURVEY.md
+    // section 8 (f).3): two pieces = 16 mantissa bits per operand, three products, error ~2^-16 relative.
+    constexpr int CO_T = COT, MR = COT / 32, NPROD = NPC == 3 ? 6 : 3, UNITS = NPROD * MR * NR, NFR = NPC * (MR + NR);
+    constexpr int LPU = (12 + UNITS - 1) / UNITS;  // raw-load pieces per unit in tap 7
+    static_assert(NPC == 3 || NPC == 2, "pieces");
+    static_assert(NFR <= UNITS && 24 % UNITS == 0, "unit schedule");
     constexpr int WBYTES = 3 * 3 * NG * COT * 16, NPIECE = WBYTES / 1024, PPW = (NPIECE + 3) / 4;  // DMA pieces per wave
     constexpr int XSL = 24 / UNITS;  // transform slots per unit (144 slots per chunk over taps 1..6)
     static_assert(COT == 64 || COT == 32, "co tile");
@@ -233,13 +238,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
             qv1 -= qm1;
         } else if (sl == 10) {
             qpk[1][i2] = cvt_pk_bf16(qv0, qv1);
-        } else if (sl == 11) {
+        } else if (NPC == 3 && sl == 11) {
             qm0 = __uint_as_float(qpk[1][i2] << 16);
             qm1 = __uint_as_float(qpk[1][i2] & 0xffff0000u);
-        } else if (sl == 12) {
+        } else if (NPC == 3 && sl == 12) {
             qv0 -= qm0;
             qv1 -= qm1;
-        } else {
+        } else if (NPC == 3) {
             qpk[2][i2] = cvt_pk_bf16(qv0, qv1);
         }
     };
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         for (int sl = 0; sl < 14; ++sl) xf(xv0, xv1, xm0, xm1, xpk, k, sl);
         if ((k & 3) == 3) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xf_write(xpk, smem, k >> 2, pl);
+            for (int pl = 0; pl < NPC; ++pl) xf_write(xpk, smem, k >> 2, pl);
         }
     }
     load_setup(nchunks > 1 ? CK : 0);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         sdma = sdma < nstages ? sdma : nstages - 1;  // past the end: repeat the last stage (harmless, keeps vmcnt uniform)
         if (t == 7) load_setup((c + 2 < nchunks ? c + 2 : nchunks - 1) * CK);
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int PI[6] = {2, 0, 1, 1, 0, 0}, PJ[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PI[6] = {NPC == 3 ? 2 : 1, 0, NPC == 3 ? 1 : 0, 1, 0, 0}, PJ[6] = {0, NPC == 3 ? 2 : 1, NPC == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             const int q = i / (MR * NR), m = (i / NR) % MR, n = i % NR;
@@ -403,7 +408,11 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
                 if (i == 11) fr(ic<11>{});
             }
 #ifndef X3S_NO_DMA
-            if (tx == 1 && (i & 3) == 1 && i < 4 * PPW) dma_piece(sdma, i >> 2);  // into the ring slot of stage sigma-1
+            if (tx == 1) {  // PPW pieces spread over the tap, into the ring slot of stage sigma-1
+#pragma unroll
+                for (int kp = 0; kp < PPW; ++kp)
+                    if (i == (kp * UNITS) / PPW) dma_piece(sdma, kp);
+            }
 #endif
 #ifndef X3S_NO_XF
             if (t >= 1 && t <= 6) {  // transform of chunk c+1: 144 slots; stream X pairs 0..7, stream Y pairs 8..15,
@@ -413,14 +422,20 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
                     if (off < 14) {
                         xf(xv0, xv1, xm0, xm1, xpk, j, off);
                         xf(yv0, yv1, ym0, ym1, ypk, 8 + j, off);
-                    } else if ((j & 3) == 3 && off < 17) {
+                    } else if ((j & 3) == 3 && off < 14 + NPC) {
                         xf_write(xpk, nbuf, j >> 2, off - 14);
                         xf_write(ypk, nbuf, (8 + j) >> 2, off - 14);
                     }
                 }
             }
 #endif
-            if (t == 7 && i >= UNITS - 12) load_piece(i - (UNITS - 12));  // raw pixels of the chunk after next
+            if (t == 7) {  // raw pixels of the chunk after next: 12 loads over the last units of the tap
+#pragma unroll
+                for (int jl = 0; jl < LPU; ++jl) {
+                    const int idx = i * LPU + jl - (UNITS * LPU - 12);
+                    if (idx >= 0) load_piece(idx);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -487,9 +502,12 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
 // block on the same CU; 75 KB of LDS and 256 registers per block.  The tap stream (MFMA + fragment reads + DMA
 // pieces + raw pixel loads interleaved unit by unit) is the one of conv_bf16x3_stream_kernel; the transform of the
 // next chunk runs at the chunk boundary because the single x tile is free only then.
-template <int PRO>
+template <int PRO, int NPC>
 __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvParams p) {
     using namespace x3s;
+    constexpr int NPROD = NPC == 3 ? 6 : 3, UNITS = NPROD * MR * NR, NFR = NPC * (MR + NR);  // see conv_bf16x3_stream_kernel
+    constexpr int LPU = (12 + UNITS - 1) / UNITS, PPW = 5;
+    static_assert(NPC == 3 || NPC == 2, "pieces");
     constexpr int RING2 = 2, WB1 = XBYTES2;  // [x tile][weight ring of two stages]: 75456 bytes, two blocks per CU
     constexpr int NL = PRO != PRO_NONE ? 12 : 8;  // VMEM loads per chunk of raw pixels (+ folded affine)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -609,13 +627,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
             qv1 -= qm1;
         } else if (sl == 10) {
             qpk[1][i2] = cvt_pk_bf16(qv0, qv1);
-        } else if (sl == 11) {
+        } else if (NPC == 3 && sl == 11) {
             qm0 = __uint_as_float(qpk[1][i2] << 16);
             qm1 = __uint_as_float(qpk[1][i2] & 0xffff0000u);
-        } else if (sl == 12) {
+        } else if (NPC == 3 && sl == 12) {
             qv0 -= qm0;
             qv1 -= qm1;
-        } else {
+        } else if (NPC == 3) {
             qpk[2][i2] = cvt_pk_bf16(qv0, qv1);
         }
     };
@@ -661,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
             for (int sl = 0; sl < 14; ++sl) xf(xv0, xv1, xm0, xm1, xpk, k, sl);
             if ((k & 3) == 3) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xf_write(xpk, smem, k >> 2, pl);
+                for (int pl = 0; pl < NPC; ++pl) xf_write(xpk, smem, k >> 2, pl);
             }
         }
     };
@@ -683,15 +701,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
     auto frag1 = [&](const unsigned (&xb)[NR], unsigned wb, auto KY, auto TX, auto R, u32x4 (&a)[3][MR], u32x4 (&bb)[3][NR])
                      __attribute__((always_inline)) {
         constexpr int ky = decltype(KY)::value, tx = decltype(TX)::value, r = decltype(R)::value;
-        constexpr int pl = r / 4, w = r % 4;
-        if constexpr (w < 2)
+        constexpr int pl = r / (MR + NR), w = r % (MR + NR);
+        if constexpr (r >= NFR) {
+        } else if constexpr (w < MR)
             asm volatile("ds_read_b128 %0, %1 offset:%2"
                          : "=v"(a[pl][w])
                          : "v"(wb), "i"(pl * (3 * NG * CO_T * 16) + tx * (NG * CO_T * 16) + w * 512));
         else
             asm volatile("ds_read_b128 %0, %1 offset:%2"
-                         : "=v"(bb[pl][w - 2])
-                         : "v"(xb[w - 2]), "i"(pl * (XPL2 * 16) + ky * (XS2 * 16) + tx * 16));
+                         : "=v"(bb[pl][w - MR])
+                         : "v"(xb[w - MR]), "i"(pl * (XPL2 * 16) + ky * (XS2 * 16) + tx * 16));
     };
     {
         auto f0 = [&](auto R) __attribute__((always_inline)) { frag1(xcur, lds_w0, ic<0>{}, ic<0>{}, R, fa[0], fb[0]); };
@@ -732,13 +751,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
         sdma = sdma < nstages ? sdma : nstages - 1;  // past the end: repeat the last stage (harmless, keeps vmcnt uniform)
         if (t == 0) load_setup((c + 1 < nchunks ? c + 1 : nchunks - 1) * CK);
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int PI[6] = {2, 0, 1, 1, 0, 0}, PJ[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PI[6] = {NPC == 3 ? 2 : 1, 0, NPC == 3 ? 1 : 0, 1, 0, 0}, PJ[6] = {0, NPC == 3 ? 2 : 1, NPC == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            const int q = i / 4, m = (i / 2) & 1, n = i & 1;
+        for (int i = 0; i < UNITS; ++i) {
+            const int q = i / (MR * NR), m = (i / NR) % MR, n = i % NR;
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][PI[q]][m]),
                                                                 __builtin_bit_cast(bf16x8, fb[cur][PJ[q]][n]), acc[m][n], 0, 0, 0);
-            if (i < 12 && t < 8) {  // next tap's fragments (the next chunk's first tap waits for the new x tile)
+            if (i < NFR && t < 8) {  // next tap's fragments (the next chunk's first tap waits for the new x tile)
                 auto fr = [&](auto R) __attribute__((always_inline)) {
                     frag1(xcur, wbn, ic<kyn>{}, ic<txn>{}, R, fa[cur ^ 1], fb[cur ^ 1]);
                 };
@@ -755,8 +774,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
                 if (i == 10) fr(ic<10>{});
                 if (i == 11) fr(ic<11>{});
             }
-            if (tx == 2 && (i & 3) == 1 && i < 20) dma_piece(sdma, i >> 2);  // into the ring slot of stage sigma
-            if (t == 0 && i >= 12) load_piece(i - 12);  // raw pixels of the next chunk
+            if (tx == 2) {  // PPW pieces spread over the tap, into the ring slot of stage sigma
+#pragma unroll
+                for (int kp = 0; kp < PPW; ++kp)
+                    if (i == (kp * UNITS) / PPW) dma_piece(sdma, kp);
+            }
+            if (t == 0) {  // raw pixels of the next chunk: 12 loads over the last units of the tap
+#pragma unroll
+                for (int jl = 0; jl < LPU; ++jl) {
+                    const int idx = i * LPU + jl - (UNITS * LPU - 12);
+                    if (idx >= 0) load_piece(idx);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -871,9 +900,9 @@ hipError_t launch_pack_conv_bf16x3(const float* w, float* dst, int Cout, int Cin
     return hipGetLastError();
 }
 
-template <int PRO>
+template <int PRO, int NPC>
 static hipError_t launch_x3_pair(const ConvParams& p, hipStream_t s) {
-    auto kern = conv_bf16x3_pair_kernel<PRO>;
+    auto kern = conv_bf16x3_pair_kernel<PRO, NPC>;
     constexpr int lds = x3s::XBYTES2 + 2 * x3::WBYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -888,9 +917,9 @@ static hipError_t launch_x3_pair(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int PRO, int COT>
+template <int PRO, int COT, int NPC>
 static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
-    auto kern = conv_bf16x3_stream_kernel<PRO, COT>;
+    auto kern = conv_bf16x3_stream_kernel<PRO, COT, NPC>;
     constexpr int lds = x3s::WB0 + x3s::RING * (3 * 3 * x3::NG * COT * 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -914,11 +943,17 @@ hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
     const bool deep = conv_bf16x3_deep(p.Cin);
     ConvParams q = p;
     q.sign_shift = conv_bf16x3_sign_shift(p.Cin);
+    if (p.pieces != 3 && p.pieces != 2) return hipErrorInvalidValue;
+#define X3_DISPATCH(PRO_)                                                                                           \
+    return !deep ? (p.pieces == 3 ? launch_x3_pair<PRO_, 3>(q, s) : launch_x3_pair<PRO_, 2>(q, s))                  \
+           : p.co_tile == 32 ? (p.pieces == 3 ? launch_x3_stream<PRO_, 32, 3>(q, s) : launch_x3_stream<PRO_, 32, 2>(q, s)) \
+                             : (p.pieces == 3 ? launch_x3_stream<PRO_, 64, 3>(q, s) : launch_x3_stream<PRO_, 64, 2>(q, s))
     switch (p.prologue) {
-        case PRO_NONE: return !deep ? launch_x3_pair<PRO_NONE>(q, s) : p.co_tile == 32 ? launch_x3_stream<PRO_NONE, 32>(q, s) : launch_x3_stream<PRO_NONE, 64>(q, s);
-        case PRO_AFFINE: return !deep ? launch_x3_pair<PRO_AFFINE>(q, s) : p.co_tile == 32 ? launch_x3_stream<PRO_AFFINE, 32>(q, s) : launch_x3_stream<PRO_AFFINE, 64>(q, s);
-        case PRO_AFFINE_SILU: return !deep ? launch_x3_pair<PRO_AFFINE_SILU>(q, s) : p.co_tile == 32 ? launch_x3_stream<PRO_AFFINE_SILU, 32>(q, s) : launch_x3_stream<PRO_AFFINE_SILU, 64>(q, s);
+        case PRO_NONE: X3_DISPATCH(PRO_NONE);
+        case PRO_AFFINE: X3_DISPATCH(PRO_AFFINE);
+        case PRO_AFFINE_SILU: X3_DISPATCH(PRO_AFFINE_SILU);
     }
+#undef X3_DISPATCH
     return hipErrorInvalidValue;
 }
 

@@ -96,6 +96,7 @@ struct r2dm_handle {
     ConvLayer in_conv_c;
     size_t cmap = 0, zero_bias = 0;
     bool cmap_ready = false;
+    int conv_pieces = 3;  // bf16 pieces per fp32 operand of the split-bf16 3x3 convolutions (r2dm_set_conv_pieces)
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
     int ada_rows = 0;
     std::map<int, size_t> ws_cache;
@@ -404,6 +405,7 @@ struct Ctx {
             p.taps = L.taps;
             p.co_tile = L.co_tile;
             p.algo = L.algo;
+            p.pieces = h->conv_pieces;
             p.prologue = pro;
             if (sink && *sink && (L.co_tile >= 64 || L.algo == ALGO_BF16X3)) {
                 p.stat = sink->p;
@@ -762,6 +764,17 @@ int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t
     return 0;
 }
 
+static int g_single_kernel_pieces = 3;  // r2dm_conv2d_ring (per-op tests)
+
+int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces) {
+    if (pieces != 2 && pieces != 3) return fail(1, "pieces must be 3 (exact split, fp32-class error) or 2 (reduced precision)");
+    if (h)
+        h->conv_pieces = pieces;
+    else
+        g_single_kernel_pieces = pieces;
+    return 0;
+}
+
 int r2dm_profile_enable(r2dm_handle* h, int32_t on) {
     if (!h) return fail(1, "null argument");
     h->prof_on = on != 0;
@@ -804,6 +817,7 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     hipStream_t st = (hipStream_t)stream;
     ConvParams p;
     p.taps = ksize * ksize;
+    p.pieces = g_single_kernel_pieces;
     p.algo = conv_pick_algo(cin, cout, p.taps);
     if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale)) p.algo = ALGO_F32;  // plain convolutions only
     p.co_tile = p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);

@@ -19,10 +19,11 @@ def count_parameters(model: torch.nn.Module) -> int:
 
 
 def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, compile: bool = False,
-                max_batch: int = 8):
+                max_batch: int = 8, precision: str = "fp32"):
     """Build the sampler from a checkpoint (utils/inference.py:20-110).
 
-    ``max_batch`` (extension) tells the HIP engine which batch size to tile its layers for."""
+    ``max_batch`` (extension) tells the HIP engine which batch size to tile its layers for; ``precision`` (extension)
+    is ``"fp32"`` (parity mode) or ``"bf16x2"`` (reduced precision, see ``EfficientUNet.set_precision``)."""
     if isinstance(ckpt, (str, Path)):
         ckpt = torch.load(ckpt, map_location="cpu")
     cfg = Config(**ckpt["cfg"])
@@ -72,6 +73,7 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
     ddpm.eval()
     ddpm.requires_grad_(False)
     ddpm.to(device)
+    ddpm.model.set_precision(precision)
 
     if compile:
         ddpm.model = torch.compile(ddpm.model)  # the ctypes call is a graph break -> runs eagerly

@@ -171,6 +171,7 @@ class EfficientUNet(nn.Module):
             self._register(e, _default_init(e, self.geometry))
         self._engine: Optional[_Engine] = None
         self._packed_for = None
+        self.precision = "fp32"
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- generic parameter tree ----------------------------------------------------------------
@@ -224,6 +225,7 @@ class EfficientUNet(nn.Module):
             return
         if self._engine is None:
             self._engine = _Engine(self.geometry, self.max_batch)
+            self.set_precision(self.precision)
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         self._check_fixed_buffers(sd)
         sd.update(self._constants(sd))
@@ -244,6 +246,7 @@ class EfficientUNet(nn.Module):
         (e.g. received through ``torch.distributed.broadcast``) without loading a state dict."""
         if self._engine is None:
             self._engine = _Engine(self.geometry, self.max_batch)
+            self.set_precision(self.precision)
         if blob.numel() != self._engine.blob_bytes():
             raise _lib.R2DMError(f"blob has {blob.numel()} bytes, engine expects {self._engine.blob_bytes()}")
         self._engine.bind(blob)
@@ -253,6 +256,20 @@ class EfficientUNet(nn.Module):
         if self._engine is None:
             self._engine = _Engine(self.geometry, self.max_batch)
         return self._engine.blob_bytes()
+
+    # -- precision ---------------------------------------------------------------------------------
+    PRECISIONS = {"fp32": 3, "bf16x2": 2}
+
+    def set_precision(self, precision: str = "fp32"):
+        """``"fp32"`` (default): 3x3 convolutions with exactly split operands, fp32-class error -- the parity mode.
+        ``"bf16x2"``: two bf16 pieces per operand (16 mantissa bits), half the matrix-pipe work -- the counterpart of the
+        reference's mixed-precision bulk sampling (sample_and_save.py:70); everything but the 3x3 convolutions stays fp32."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {precision!r}")
+        self.precision = precision
+        if self._engine is not None:
+            _lib.check(_lib.lib().r2dm_set_conv_pieces(self._engine.h, self.PRECISIONS[precision]))
+        return self
 
     # -- measurement aid ---------------------------------------------------------------------------
     def profile_convs(self, on: bool):

@@ -5,7 +5,8 @@ files ``samples_{seed:010d}.pth`` holding a (5,H,W) [depth, x, y, z, reflectance
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N sample_and_save.py ...`` -- one process
 per MI355X, seeds sharded contiguously (what Accelerate's split_batches DataLoader does in the reference,
 :25-46), weights packed once on rank 0 and broadcast over RCCL/xGMI, no collective in the sampling loop.
-Precision: fp32 (the reference runs this script under fp16 autocast, :70; reduced precision is a later row)."""
+Precision: fp32-class by default; ``--precision bf16x2`` selects the reduced-precision convolutions (the reference runs this
+script under fp16 autocast, :70 -- bf16x2 keeps 16 mantissa bits per operand, fp16 autocast 11)."""
 import os
 from argparse import ArgumentParser
 from pathlib import Path
@@ -26,7 +27,8 @@ def sample(args):
 
         td.init_process_group("nccl", device_id=device)
 
-    ddpm, lidar_utils, cfg = r2dm_amd.setup_model(args.ckpt, show_info=rank == 0, max_batch=args.batch_size)
+    ddpm, lidar_utils, cfg = r2dm_amd.setup_model(args.ckpt, show_info=rank == 0, max_batch=args.batch_size,
+                                                  precision=args.precision)
     ddpm.to(device)
     lidar_utils.to(device)
     broadcast_packed_weights(ddpm.model, device, src=0)
@@ -58,4 +60,5 @@ if __name__ == "__main__":
     parser.add_argument("--num_samples", type=int, default=10_000)
     parser.add_argument("--num_steps", type=int, default=256)
     parser.add_argument("--mode", choices=["ddpm", "ddim"], default="ddpm")
+    parser.add_argument("--precision", choices=["fp32", "bf16x2"], default="fp32")
     sample(parser.parse_args())

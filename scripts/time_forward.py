@@ -10,7 +10,7 @@ dev = "cuda"
 res = tuple(int(v) for v in os.environ.get("RES", "64,1024").split(","))
 ck = synthetic.synthetic_checkpoint(seed=0, resolution=res)
 for B in [int(b) for b in os.environ.get("BATCHES", "1,8").split(",")]:
-    ddpm, _, _ = r2dm_amd.setup_model(ck, device=dev, show_info=False, max_batch=B)
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=dev, show_info=False, max_batch=B, precision=os.environ.get("PRECISION", "fp32"))
     x = torch.randn(B, 2, *res, device=dev)
     c = torch.zeros(B, device=dev)
     t0 = time.perf_counter(); y = ddpm.model(x, c); torch.cuda.synchronize()

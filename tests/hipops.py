@@ -8,6 +8,11 @@ def _st(t):
     return _lib.stream_ptr(t.device)
 
 
+def set_conv_pieces(n):
+    """Mode of the single-kernel conv entry: 3 = exact split (default), 2 = reduced precision."""
+    _lib.check(_lib.lib().r2dm_set_conv_pieces(None, n))
+
+
 def conv2d_ring(x, w, b, aff=None, prologue=0, residual=None, scale=None):
     L = _lib.lib()
     B, cin, H, W = x.shape

@@ -72,6 +72,31 @@ def test_conv3x3_repeatable_at_full_size(H, cin, cout, h, w, B):
     assert max_abs(y0[bs:].cpu(), ref.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 256), (128, 128, 8, 128), (256, 256, 16, 256), (512, 512, 8, 128)])
+def test_conv3x3_reduced_precision_mode(O, H, cin, cout, h, w):
+    """(f).3: two bf16 pieces per operand (16 mantissa bits), three products.  Tolerance class of its own: the error
+    against fp64 must be < 1e-4 on O(1) outputs and at least 100x smaller than that of the same
+    convolution under torch's bf16 autocast -- the reduced precision the reference's bulk mode accepts (fp16 there).
+    Measured: 2.1e-5 vs 4e-6 (exact split) vs 2.9e-2 (bf16 autocast)."""
+    import torch.nn.functional as F
+
+    x, wt, b = rnd(1, 2, cin, h, w), rnd(2, cout, cin, 3, 3) / math.sqrt(9 * cin), rnd(3, cout)
+    ref = O.conv_ring(x.double(), wt.double(), b.double())
+    H.set_conv_pieces(2)
+    try:
+        y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    finally:
+        H.set_conv_pieces(3)
+    y3 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    xp = F.pad(F.pad(x, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ybf = F.conv2d(xp, wt, b).float()
+    e2, e3, ebf = max_abs(y, ref), max_abs(y3, ref), max_abs(ybf, ref)
+    print(f"conv {cin}->{cout}: max err  exact-split {e3:.2e}  two-piece {e2:.2e}  bf16 autocast {ebf:.2e}")
+    assert e3 < 1e-5 < e2  # the mode switch took effect
+    assert e2 < 1e-4 and e2 * 100 < ebf
+
+
 def test_conv3x3_batch_tiling_variants(O, H):
     # large batch*pixels switches Cout%128==0 layers to the 128-channel tile (conv_pick_co_tile)
     x, wt, b = rnd(4, 8, 32, 64, 256), rnd(5, 128, 32, 3, 3) / math.sqrt(288), rnd(6, 128)

@@ -270,6 +270,37 @@ def test_batch32_ddim_runs_and_is_seed_determined():
     assert (a[8:16] - b).pow(2).mean().sqrt() < 5e-5 and max_abs(a[8:16], b) < 5e-2
 
 
+def test_reduced_precision_mode(golden):
+    """(f).3 reduced-precision sampling (`precision="bf16x2"`): the 3x3 convolutions keep 16 mantissa bits per operand.
+    Its own tolerance class: U-Net output within 2e-4 of the reference (golden, fp32; measured 1.3e-5) and at least 100x
+    closer to it than the oracle run under torch's bf16 autocast (the kind of precision the reference's bulk mode
+    accepts); 8-step DDPM final sample within 5e-4 of the reference's (measured 4.7e-5); switching back restores the
+    parity mode bit for bit."""
+    from oracle import r2dm_oracle as O
+
+    g, gs = golden("unet"), golden("sample_ddpm")
+    ddpm, _ = build(resolution=GOLDEN_RES)
+    net = ddpm.model
+    x, c = g["x"].to(DEV), torch.full((2,), g["conds"].tolist()[2], device=DEV)
+    y32 = net(x, c).cpu()
+    net.set_precision("bf16x2")
+    y2 = net(x, c).cpu()
+    Tape(ddpm, gs["noise"])
+    s2 = ddpm.sample(batch_size=2, num_steps=8, progress=False, rng=None).cpu()
+    net.set_precision("fp32")
+    assert torch.equal(net(x, c).cpu(), y32)
+    sd = O.strip_prefix(synthetic_ckpt(resolution=GOLDEN_RES)["ema_weights"])
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ybf = O.unet_forward(sd, O.UNetConfig(resolution=GOLDEN_RES), g["x"], c.cpu()).float()
+    e2, ebf, es = max_abs(y2, g["y"][2]), max_abs(ybf, g["y"][2]), max_abs(s2, gs["out"][-1])
+    print(f"reduced precision: U-Net max err {e2:.2e} (bf16-autocast oracle {ebf:.2e}; fp32 mode {max_abs(y32, g['y'][2]):.2e}); "
+          f"final 8-step sample max err {es:.2e}")
+    assert max_abs(y32, g["y"][2]) < 1e-5 and max_abs(y32, g["y"][2]) < e2 < 2e-4 and e2 * 100 < ebf  # measured 1.3e-5
+    assert es < 5e-4  # measured 4.7e-5
+    with pytest.raises(ValueError):
+        net.set_precision("fp8")
+
+
 def test_repaint_kernels_replay_reference_ops():
     """r2dm_repaint_blend / r2dm_q_step vs the reference expressions evaluated op by op by torch on the same GPU
     (continuous_time.py:175,186-189,296): bit-exact (no FMA contraction in the kernels)."""

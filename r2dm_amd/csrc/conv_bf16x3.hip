@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         if (tx == 1) {
             // B_sigma: everybody is past tap (sigma, 0).  Before it: this wave's pieces of stage sigma+1 have landed
             // (only stage sigma+2's PPW may still be in flight) and its x-tile writes are done.
-#ifndef X3S_NO_BARRIER
+#ifndef X3S_NO_BARRIER  // (X3S_NO_*: ablation switches for scripts/build_variant.sh -- timing experiments, wrong results)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -363,11 +363,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
                 }
             }
         } else {
-#ifdef X3S_LGKM_RELAX
-            asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-#else
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tap's fragments (issued a tap ago)
-#endif
         }
         const unsigned wbn = lds_w0 + (unsigned)(((t < 8 ? sigma + (kyn != ky ? 1 : 0) : sigma + 1) & (RING - 1)) * WBYTES);
         int sdma = sigma + 3;

@@ -220,6 +220,29 @@ def test_sample_full_size_vs_oracle():
         assert mx < 4e-3, rows
 
 
+def test_north_star_final_sample_parity():
+    """BASELINE.json: "outputs match the reference PyTorch sampler on identical noise ... per-pixel output delta
+    < 1e-4".  Full-size 64x1024 DDPM, 48 steps (the 256-step run of scripts/validate_256.py gives max 3.7e-6, rms
+    2.6e-7; 48 steps keep the CPU oracle at ~30 s): the FINAL sample against the oracle -- the reference's arithmetic,
+    torch fp32 on the CPU -- on the same noise tape.  Intermediate steps near t = 1 are ill-conditioned (see
+    test_sample_golden); the errors contract as alpha_t grows and the finished sample agrees to a few 1e-6."""
+    import r2dm_amd
+    from oracle import r2dm_oracle as O
+
+    S = 48
+    ddpm, _ = build()
+    rng = r2dm_amd.setup_rng([11], DEV)
+    tape = [ddpm.randn(1, 2, 64, 1024, rng=rng, device=DEV) for _ in range(S + 1)]
+    Tape(ddpm, tape)
+    got = ddpm.sample(batch_size=1, num_steps=S, progress=False, rng=None).cpu()
+    sd = O.strip_prefix(synthetic_ckpt()["ema_weights"])
+    cfg = O.UNetConfig()
+    want = O.sample_continuous(lambda x, c: O.unet_forward(sd, cfg, x, c), (1, 2, 64, 1024), S, noises=[z.cpu() for z in tape])
+    mx, r = max_abs(got, want), rms(got, want)
+    print(f"north star: {S}-step final sample max|hip - oracle| = {mx:.2e}, rms {r:.2e}")
+    assert mx < 1e-4 and r < 2e-6
+
+
 def test_lidar_postprocess_matches_members(golden, small):
     lidar = small[1]
     g = golden("lidar")

@@ -6,6 +6,9 @@ import numpy as np
 import pytest
 import torch
 
+# the fp32 / fp64 CPU oracles (torch + oneDNN) get SLOWER beyond a few dozen threads on the 256-core GPU hosts
+torch.set_num_threads(min(32, os.cpu_count() or 1))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

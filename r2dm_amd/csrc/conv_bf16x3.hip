@@ -569,7 +569,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
     // into 14 micro-slices of two INDEPENDENT instructions, one micro-slice per unit: a dependent VALU chain inside
     // one MFMA shadow would stall the wave's in-order issue beyond it.
     // (plain scalars, not a struct array: hipcc parks an indexed struct array in scratch memory)
-    float xv0 = 0.f, xv1 = 0.f, xm0 = 0.f, xm1 = 0.f;
     unsigned xpk[3][4];  // the three planes of the pixel being transformed (4 channel pairs each)
 
     // raw-load pieces (12 per chunk): i < 8 pixel quads, i >= 8 the folded GroupNorm affine
@@ -668,15 +667,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     // ---- prologue: weight stages 0 and 1 in flight, chunk 0 transformed into the x tile ----
+    // whole tile at once (prologue, chunk boundaries): the four channel pairs of a pixel advance slice by slice together,
+    // four independent dependency chains instead of one
     auto transform_all = [&]() __attribute__((always_inline)) {
+        float v0[4], v1[4], m0[4], m1[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int sl = 0; sl < 14; ++sl) xf(xv0, xv1, xm0, xm1, xpk, k, sl);
-            if ((k & 3) == 3) {
+            for (int sl = 0; sl < 14; ++sl)
 #pragma unroll
-                for (int pl = 0; pl < NPC; ++pl) xf_write(xpk, smem, k >> 2, pl);
-            }
+                for (int i2 = 0; i2 < 4; ++i2) xf(v0[i2], v1[i2], m0[i2], m1[i2], xpk, 4 * e + i2, sl);
+#pragma unroll
+            for (int pl = 0; pl < NPC; ++pl) xf_write(xpk, smem, e, pl);
         }
     };
 #pragma unroll

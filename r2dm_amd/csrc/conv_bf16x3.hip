@@ -806,7 +806,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
             // chunk boundary: the single x tile is rewritten while the other block of this CU owns the matrix pipe
             __builtin_amdgcn_s_barrier();  // every wave has its last fragments of this chunk in registers
             asm volatile("" ::: "memory");
+#ifndef X3P_NO_XF
             transform_all();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

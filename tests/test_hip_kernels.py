@@ -3,6 +3,7 @@ C ABI.  Tolerances are absolute, fp32: a K-term fp32 dot product with |terms| ~ 
 ~sqrt(K)*6e-8 of roundoff, and the oracle (MIOpen-free torch CPU ops) has the same amount with a
 different summation order, so 'equal' means a few 1e-6 at K = 4608."""
 import math
+import os
 
 import pytest
 import torch
@@ -72,6 +73,7 @@ def test_conv3x3_repeatable_at_full_size(H, cin, cout, h, w, B):
     assert max_abs(y0[bs:].cpu(), ref.cpu()) < 2e-5
 
 
+@pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 256), (128, 128, 8, 128), (256, 256, 16, 256), (512, 512, 8, 128)])
 def test_conv3x3_reduced_precision_mode(O, H, cin, cout, h, w):
     """(f).3: two bf16 pieces per operand (16 mantissa bits), three products.  Tolerance class of its own: the error

@@ -157,14 +157,17 @@ def main():
         line = {
             "metric": "range-images/sec (64x1024, 256-step DDPM)", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f32 (3x3 conv operands split exactly into 3 bf16 pieces on the bf16 matrix pipe, fp32 accumulate; everything else plain fp32)"
-                      if args.precision == "fp32" else
-                      "REDUCED PRECISION bf16x2 (3x3 conv operands = 2 bf16 pieces, 16 mantissa bits; optional mode, not the parity mode)"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x2 (REDUCED PRECISION, optional mode)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 64x1024x2 range/reflectance, 256-step DDPM, batch 8 per GPU; "
                                    "timed = one sample() call of --steps reverse steps, value scaled to 256 steps",
                        "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
-                       "sampler_steps": SAMPLER_STEPS, "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
+                       "sampler_steps": SAMPLER_STEPS,
+                       "arithmetic": ("fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply on the bf16 matrix "
+                                      "pipe with every fp32 operand split exactly into 3 bf16 pieces (6 products, fp32-class error)"
+                                      if args.precision == "fp32" else
+                                      "fp32 tensors and accumulation; 3x3 convolution operands = 2 bf16 pieces (16 mantissa bits, 3 products)"),
+                       "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
             "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": peak_split / 1e12, "unit": "TFLOP/s",
                          "frac": conv["tflops"] * 1e12 / peak_split, "traffic": pmc_traffic(),
                          "peak_definition": "dense bf16 MFMA peak 2500 TF/s / %d bf16 products per algorithmic fp32 product" % (6 if args.precision == "fp32" else 3),

@@ -84,9 +84,9 @@ int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* 
  *    matrix-pipe work.  Everything else stays fp32.  h == NULL sets the mode of the single-kernel entry r2dm_conv2d_ring. */
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
 
-/* -- measurement aid (bench.py): when enabled, every launch of the dominant kernel class -- the MFMA
- *    convolution, conv_mfma_kernel, 60 launches per forward -- is bracketed by hipEvents recorded on the
- *    caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed
+/* -- measurement aid (bench.py): when enabled, every convolution launch of a forward -- the split-bf16 3x3 kernels
+ *    (conv_bf16x3_*), the fp32-MFMA kernel (conv_mfma_kernel: 1x1, in_conv) and the direct out_conv kernel, 64
+ *    launches per forward -- is bracketed by hipEvents recorded on the caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed
  *    ALGORITHMIC flops (2*B*Cout*Cin*k*k*H*W per launch) and the number of launches, then resets. */
 int r2dm_profile_enable(r2dm_handle* h, int32_t on);
 int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_t* launches);

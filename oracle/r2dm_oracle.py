@@ -8,10 +8,9 @@ inputs live on) of the reference's hot path:
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
 import this module; the product (``r2dm_amd``) never does and has no CPU fallback.
 
-Pinning: this oracle is checked against the real reference (imported from
-/root/reference in the dev container) by ``oracle/check_against_reference.py`` and
-against the golden vectors that script's sibling ``tests/golden/make_golden.py``
-captured from the reference (``tests/test_oracle_golden.py``).  The reference itself
+Pinning: ``tests/golden/make_golden.py`` imports the real reference (from
+/root/reference, dev container only) and captures its inputs/outputs as golden vectors;
+``tests/test_oracle_golden.py`` checks every function of this oracle against them.  The reference itself
 ships no tests or golden vectors.
 
 Every function names the reference file:line whose arithmetic it restates.  All

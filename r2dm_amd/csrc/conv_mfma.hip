@@ -525,7 +525,8 @@ int conv_pick_algo(int Cin, int Cout, int taps) {
         return e && e[0] == 'f';
     }();
     if (force_f32) return ALGO_F32;
-    if (conv_direct_supported(Cout, taps) && Cin <= 1024) return ALGO_DIRECT;
+    // the direct kernel keeps all Cout*Cin*9 weights in LDS (32 KiB budget, launch_conv_direct): larger shapes use the MFMA path
+    if (conv_direct_supported(Cout, taps) && (long)Cout * Cin * 36 <= 32768) return ALGO_DIRECT;
     return conv_bf16x3_supported(Cin, Cout, taps) ? ALGO_BF16X3 : ALGO_F32;
 }
 

@@ -335,13 +335,16 @@ struct Ctx {
     struct Sink {
         double* p = nullptr;
         int C = 0, cpg = 0, slots = 0;  // C: channels of the normalised (possibly concatenated) tensor
-        explicit operator bool() const { return p != nullptr; }
+        bool incomplete = false;        // a producer could not emit its share: the consumer runs the streaming pass instead
+        explicit operator bool() const { return p != nullptr && !incomplete; }
     };
     Sink make_sink(int C_total, int H, int W) {
         Sink k;
         const int G = h->cfg.gn_num_groups;
         const int cpg = C_total / G;
-        if (C_total % G || cpg % 8 || cpg > 64) return k;  // shapes the epilogue reduction does not cover: separate pass
+        // the epilogue reduction (conv_epilogue.h) merges whole 8-channel blocks of ONE wave: groups must be 8, 16, 32 or
+        // 64 channels so that they never straddle waves; anything else takes the separate streaming pass
+        if (C_total % G || cpg < 8 || cpg > 64 || (cpg & (cpg - 1))) return k;
         k.C = C_total;
         k.cpg = cpg;
         k.slots = conv_stat_slots(H, W);
@@ -352,6 +355,9 @@ struct Ctx {
         if (k.p) ar->release(k.p);
         k.p = nullptr;
     }
+    // which convolution kernels write fused statistics: the split-bf16 kernels and the fp32-MFMA kernel with >= 64-channel
+    // tiles; the 32-channel fp32 tile (Cout <= 32) and the direct kernel do not
+    static bool emits_stats(const ConvLayer& L) { return L.algo == ALGO_BF16X3 || (L.algo == ALGO_F32 && L.co_tile >= 64); }
     float2* finalize(const Sink& k, int H, int W, const float* gamma, const float* beta, const float* ada) {
         float2* aff = (float2*)ar->alloc((size_t)B * k.C * sizeof(float2));
         if (!dry()) {
@@ -385,6 +391,10 @@ struct Ctx {
         y.H = H;
         y.W = W;
         y.p = dst ? dst : (float*)ar->alloc(y.bytes(B));
+        // (decided in the dry walk as well: the consumer's choice between finalize and the streaming pass changes the
+        // allocation sequence, which must be the same in both walks)
+        const bool fused_stats = sink && sink->p && emits_stats(L);
+        if (sink && sink->p && !fused_stats) const_cast<Sink*>(sink)->incomplete = true;
         if (!dry()) {
             ConvParams p;
             p.x = x;
@@ -407,7 +417,7 @@ struct Ctx {
             p.algo = L.algo;
             p.pieces = h->conv_pieces;
             p.prologue = pro;
-            if (sink && *sink && (L.co_tile >= 64 || L.algo == ALGO_BF16X3)) {
+            if (fused_stats) {
                 p.stat = sink->p;
                 p.stat_G = h->cfg.gn_num_groups;
                 p.stat_goff = goff;
@@ -518,7 +528,7 @@ struct Ctx {
             cur = nxt;
             have = true;
             carry = next;
-            carry_owned = (bool)next;
+            carry_owned = next.p != nullptr;
         }
         if (s.attn) {
             Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff);
@@ -642,6 +652,10 @@ int check_config(const r2dm_config& c) {
         if (Cl[i] % c.gn_num_groups) return fail(1, "channels %d not divisible by %d groups", Cl[i], c.gn_num_groups);
     for (int i = 1; i <= 3; ++i)  // concat seam must fall on a group boundary: 2*C / G divides C
         if (Cl[i] % (2 * Cl[i] / c.gn_num_groups)) return fail(1, "GroupNorm group straddles the skip concat");
+    // an up stage whose concatenated input has as many channels as its output would take the identity skip on a
+    // two-source tensor (reference: nn.Identity on the concatenation); the fused residual reads one source only
+    for (int i = 1; i <= 3; ++i)
+        if (2 * Cl[i] == Cl[i - 1]) return fail(1, "channel_multiplier: 2*%d == %d makes u_block%d's first skip an identity over a concatenation (unsupported)", Cl[i], Cl[i - 1], i);
     const int N = (c.height / 8) * (c.width / 8);
     if (!attention_supported(Cl[4], c.attn_num_heads, N) || !attention_supported(Cl[3], c.attn_num_heads, N))
         return fail(1, "attention: head_dim must be 32 or 64 and tokens a multiple of 32 (got C=%d/%d, heads=%d, N=%d)",

@@ -50,26 +50,31 @@ def broadcast_packed_weights(model, device, src: int = 0) -> None:
         model.adopt_packed_weights(blob)
 
 
-def sample_sharded(sample_fn: Callable[[List[int]], torch.Tensor], seeds: Sequence[int], gather: bool = True):
+def sample_sharded(sample_fn: Callable[[List[int]], torch.Tensor], seeds: Sequence[int], gather: bool = True,
+                   device=None):
     """Run ``sample_fn(my_seeds) -> (n_local, ...)`` on this rank's shard; optionally all-gather the
-    per-seed results (in global seed order) on every rank."""
+    per-seed results (in global seed order) on every rank.  ``device``: where the gather buffers live (default: the
+    current CUDA device under the NCCL/RCCL backend, CPU under gloo) -- it must be the same kind on every rank, also
+    on ranks whose shard is empty (fewer seeds than ranks)."""
     td = _dist()
     world = td.get_world_size() if td else 1
     rank = td.get_rank() if td else 0
+    seeds = list(seeds)
     mine = shard_seeds(seeds, rank, world)
     out = sample_fn(mine) if mine else None
-    if not gather or world == 1:
+    if not gather or world == 1 or not seeds:
         return out, mine
     sizes = [len(shard_seeds(seeds, r, world)) for r in range(world)]
-    probe = out if out is not None else None
-    shape = [None]
-    td.broadcast_object_list(shape if rank else [tuple(probe.shape[1:])], src=0)
-    tail = shape[0] if rank else tuple(probe.shape[1:])
-    dev = out.device if out is not None else torch.device("cpu")
-    pad = max(sizes)
-    buf = torch.zeros(pad, *tail, device=dev, dtype=torch.float32)
+    if device is None:
+        device = (torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu"))
+    device = torch.device(device)
+    # rank 0 always owns a non-empty shard (the first len % world ranks get the extra seeds): it announces shape + dtype
+    meta = [(tuple(out.shape[1:]), out.dtype) if rank == 0 else None]
+    td.broadcast_object_list(meta, src=0)
+    tail, dtype = meta[0]
+    buf = torch.zeros(max(sizes), *tail, device=device, dtype=dtype)
     if out is not None:
-        buf[: len(mine)] = out
+        buf[: len(mine)] = out.to(device)
     parts = [torch.empty_like(buf) for _ in range(world)]
     td.all_gather(parts, buf)
     return torch.cat([p[:n] for p, n in zip(parts, sizes)]), mine

@@ -68,7 +68,7 @@ def test_shard_seeds_partition():
     assert shard_seeds(list(range(64)), 3, 8) == list(range(24, 32))  # BASELINE configs[3]: 8 seeds per GPU
 
 
-@pytest.mark.parametrize("seeds", [[0, 1, 2, 3, 4, 5], [10, 11, 12, 13, 14]])
+@pytest.mark.parametrize("seeds", [[0, 1, 2, 3, 4, 5], [10, 11, 12, 13, 14], [7]])  # [7]: rank 1 has an empty shard
 def test_two_ranks_match_single_process(tmp_path, seeds):
     blob = torch.randn(1024, generator=torch.Generator().manual_seed(42)).view(torch.uint8).clone()
     want = _tiny_sampler(blob)(seeds)

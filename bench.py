@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""Benchmark: range-images/sec of the DDPM reverse-process sampler (BASELINE.json metric).
+"""Benchmark: range-images/sec of the reverse-process sampler (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,4}]
 
-A "step" (driver vocabulary) is ONE DDPM reverse step over the whole per-GPU batch: one U-Net forward
-(r2dm_unet_forward) + RNG draw + fused posterior update.  The workload is BASELINE.json configs[1]:
-64x1024x2, batch 8 per GPU, DDPM; throughput in images/s is quoted for the 256-step sampler, i.e.
-value = n_gpus * batch / (256 * seconds_per_step).  Timing the K steps inside ONE sample() call of K
-steps (default K = 16 so the default run finishes in seconds; --steps 256 times the full sampler) is
-exact for this metric because the per-step work is independent of the step index.
-For N > 1 launch under torch.distributed.run (one rank per GPU): rank 0 packs the weights, the packed
-blob is broadcast over RCCL/xGMI, every rank samples its own seeds; no collective in the step loop.
+A "step" (driver vocabulary) is ONE reverse step over the whole per-GPU batch: one U-Net forward
+(r2dm_unet_forward) + RNG draw + fused posterior update.  Workloads (BASELINE.json `configs`):
+
+    --config 1 (default, the metric's configuration)  64x1024x2, batch 8 per GPU, DDPM, 256-step sampler
+    --config 2                                        64x1024x2, batch 32 per GPU, DDIM (eta 0), 32-step sampler
+    --config 4                                        128x2048x2, batch 2 per GPU (16 over 8 GPUs), DDPM, 256-step sampler
+
+Throughput in images/s is quoted for the configuration's full sampler, value = n_gpus * batch / (S * seconds_per_step);
+timing K steps inside ONE sample() call of K steps (default K = 16 so the default run finishes in seconds; --steps 256
+times the full sampler) is exact for this metric because the per-step work does not depend on the step index.
+For N > 1 launch under torch.distributed.run (one rank per GPU): rank 0 packs the weights, the packed blob is
+broadcast over RCCL/xGMI, every rank samples its own seeds; no collective in the step loop.
+
+Two baselines ride on the same JSON line at N = 1 (rank 0): `cpu_baseline` = the oracle (torch CPU ops) on the host
+cores, and `torch_rocm_baseline` = the same oracle on the MI355X through stock PyTorch-ROCm (MIOpen / rocBLAS) -- the
+stand-in for north_star's "reference single-GPU PyTorch sampler" (the reference's own files never travel to the GPU
+box; the oracle is pinned to it by tests/golden).
 """
 import argparse
 import json
@@ -23,48 +32,79 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-RES = (64, 1024)
-BATCH = 8            # per GPU (BASELINE configs[1] / configs[3])
-SAMPLER_STEPS = 256  # the metric's sampler length
-FLOP_PER_IMAGE_STEP = 234.52e9  # SURVEY.md section 8(d), 2*MAC
+# name -> (resolution, per-GPU batch, sampler steps, mode, algorithmic FLOP per image-step [SURVEY.md section 8(d), 2*MAC])
+CONFIGS = {
+    1: dict(res=(64, 1024), batch=8, sampler_steps=256, mode="ddpm", flop=234.52e9,
+            metric="range-images/sec (64x1024, 256-step DDPM)",
+            workload="BASELINE configs[1]: 64x1024x2 range/reflectance, 256-step DDPM, batch 8 per GPU"),
+    2: dict(res=(64, 1024), batch=32, sampler_steps=32, mode="ddim", flop=234.52e9,
+            metric="range-images/sec (64x1024, 32-step DDIM)",
+            workload="BASELINE configs[2]: 64x1024x2 range/reflectance, 32-step DDIM (eta 0), batch 32 per GPU"),
+    4: dict(res=(128, 2048), batch=2, sampler_steps=256, mode="ddpm", flop=977.92e9,
+            metric="range-images/sec (128x2048, 256-step DDPM)",
+            workload="BASELINE configs[4] geometry: 128x2048x2, 256-step DDPM, batch 2 per GPU (16 over 8 GPUs)"),
+}
 PEAK_FP32 = 157.3e12            # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16 = 2500e12             # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # The 3x3 convolutions (96 % of the FLOPs) run on the bf16 matrix pipe with every fp32 operand split exactly into three
 # bf16 pieces and six piece-products per fp32 product (r2dm_amd/csrc/conv_bf16x3.hip): the hardware ceiling for the
 # ALGORITHMIC fp32 FLOPs of that kernel is the dense bf16 peak / 6.
-PEAK_SPLIT = PEAK_BF16 / 6
 
 
-def cpu_baseline(ck):
+def oracle_net(ck, res, device):
+    from oracle import r2dm_oracle as O
+
+    sd = {k: v.to(device) for k, v in O.strip_prefix(ck["ema_weights"]).items()}
+    cfg = O.UNetConfig(resolution=res)
+    return O, (lambda x, c: O.unet_forward(sd, cfg, x, c))
+
+
+def cpu_baseline(ck, cf):
     """The oracle (a torch-op restatement of the reference, pinned to it by tests/golden) on the host cores:
-    BASELINE configs[0] shape -- 64x1024, batch 1, DDPM -- bounded to a few steps (~10-20 s of CPU work).
+    BASELINE configs[0] shape -- batch 1, same resolution and sampler -- bounded to a few steps (~10-20 s of CPU work).
     Thread count: oneDNN's fp32 convolutions at batch 1 do not scale past ~16 threads on this host class
     (measured on the 256-core GPU box: 0.26 s/forward at 16 threads, 0.63 s at 32, 1.3 s at 64, 5.1 s at 128),
     so the baseline uses min(16, cores) and reports that as `cores`."""
-    from oracle import r2dm_oracle as O
-
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    sd = O.strip_prefix(ck["ema_weights"])
-    cfg = O.UNetConfig(resolution=RES)
-    net = lambda x, c: O.unet_forward(sd, cfg, x, c)
+    O, net = oracle_net(ck, cf["res"], "cpu")
     rng = [torch.Generator().manual_seed(0)]
+    n = 16 if cf["res"] == (64, 1024) else 4
     with torch.inference_mode():
-        O.sample_continuous(net, (1, 2, *RES), 1, rng=rng)  # warm-up
-        n = 16
+        O.sample_continuous(net, (1, 2, *cf["res"]), 1, rng=rng, mode=cf["mode"])  # warm-up
         t0 = time.perf_counter()
-        O.sample_continuous(net, (1, 2, *RES), n, rng=rng)
+        O.sample_continuous(net, (1, 2, *cf["res"]), n, rng=rng, mode=cf["mode"])
         dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt / n * SAMPLER_STEPS), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU ops, fp32) sample(batch=1, {n} DDPM steps) at 64x1024 on {cores} threads "
-                      f"of {os.cpu_count()} host cores, {dt / n:.3f} s/step, scaled to the 256-step sampler"}
+    return {"value": 1.0 / (dt / n * cf["sampler_steps"]), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU ops, fp32) sample(batch=1, {n} {cf['mode'].upper()} steps) at {cf['res'][0]}x{cf['res'][1]} on "
+                      f"{cores} threads of {os.cpu_count()} host cores, {dt / n:.3f} s/step, scaled to the {cf['sampler_steps']}-step sampler"}
+
+
+def torch_rocm_baseline(ck, cf, B, dev):
+    """The same oracle evaluated by stock PyTorch-ROCm on the MI355X (MIOpen convolutions, rocBLAS attention), fp32,
+    same batch: what running the reference's PyTorch sampler on this GPU costs.  One warm-up step (MIOpen kernel
+    selection), then a bounded number of steps timed with a device synchronize on both sides."""
+    O, net = oracle_net(ck, cf["res"], dev)
+    rng = [torch.Generator(device=dev).manual_seed(i) for i in range(B)]
+    shape = (B, 2, *cf["res"])
+    n = 3
+    with torch.inference_mode():
+        O.sample_continuous(net, shape, 1, rng=rng, mode=cf["mode"], device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        O.sample_continuous(net, shape, n, rng=rng, mode=cf["mode"], device=dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": B / (dt / n * cf["sampler_steps"]), "unit": "images/s", "ms_per_step": dt / n * 1e3,
+            "kind": "oracle via PyTorch-ROCm (torch %s: MIOpen / rocBLAS, fp32, eager)" % torch.__version__,
+            "sample": f"sample(batch={B}, {n} {cf['mode'].upper()} steps after 1 warm-up step), scaled to the {cf['sampler_steps']}-step sampler"}
 
 
 def pmc_traffic():
     """HBM bytes per conv launch from the committed PMC passes (scripts/summarize_profile.py); PMC counters cannot be
     collected from inside the timed process, so this is the figure of the last profiled run of this same command."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
             return float(json.load(f)["bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
@@ -75,12 +115,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1, help="BASELINE.json configs[i] (see module docstring)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "bf16x2"], default="fp32",
                     help="fp32 (default): the parity mode BASELINE.json's metric is quoted on.  bf16x2: the optional "
                          "reduced-precision sampling mode (SURVEY.md section 8 (f).3) -- NOT the headline number")
+    ap.add_argument("--seed-base", type=int, default=0, help="first global seed (tests: reproduce one rank's shard alone)")
+    ap.add_argument("--dump-samples", default=None, help="directory: every rank saves {seeds, samples} of the timed call (tests)")
     args = ap.parse_args()
+    cf = CONFIGS[args.config]
 
     import r2dm_amd
     from r2dm_amd import synthetic
@@ -100,16 +145,18 @@ def main():
         td.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     from r2dm_amd.distributed import broadcast_packed_weights, shard_seeds
 
-    B = args.batch
+    B = args.batch or cf["batch"]
+    RES = cf["res"]
     ck = synthetic.synthetic_checkpoint(seed=0, resolution=RES)
     ddpm, lidar, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=B, precision=args.precision)
-    peak_split = PEAK_BF16 / (6 if args.precision == "fp32" else 3)
+    nprod = 6 if args.precision == "fp32" else 3
+    peak_split = PEAK_BF16 / nprod
     ddpm.to(dev)
     broadcast_packed_weights(ddpm.model, dev, src=0)  # rank 0 packs, everyone else adopts the blob
-    seeds = shard_seeds(list(range(B * world)), rank, world)
+    seeds = shard_seeds(list(range(args.seed_base, args.seed_base + B * world)), rank, world)
 
     def run(steps):
-        return ddpm.sample(batch_size=B, num_steps=steps, progress=False, rng=r2dm_amd.setup_rng(seeds, dev))
+        return ddpm.sample(batch_size=B, num_steps=steps, progress=False, mode=cf["mode"], rng=r2dm_amd.setup_rng(seeds, dev))
 
     def barrier():
         if dist:
@@ -117,7 +164,6 @@ def main():
         torch.cuda.synchronize()
 
     run(max(args.warmup, 1))  # warm-up: W untimed steps (also sizes the workspace)
-    # per-kernel timing of the dominant kernel class needs a profiler; here: wall + HIP events around the loop
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -127,14 +173,17 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(out).all()
     gpu_ms = ev0.elapsed_time(ev1)
+    if args.dump_samples:
+        os.makedirs(args.dump_samples, exist_ok=True)
+        torch.save({"seeds": seeds, "samples": out.cpu()}, os.path.join(args.dump_samples, f"rank{rank}.pt"))
 
-    # Dominant kernel (conv_mfma_kernel, ~96 % of the FLOPs and of the step time): an extra, untimed pass of a few
-    # steps with every conv launch bracketed by HIP events on the sampling stream (r2dm_profile_*).
+    # Dominant kernel class (the convolution launches, ~96 % of the FLOPs and of the step time): an extra, untimed pass
+    # of a few steps with every conv launch bracketed by HIP events on the sampling stream (r2dm_profile_*).
     conv = None
     if rank == 0:
         ddpm.model.profile_convs(True)
@@ -142,47 +191,52 @@ def main():
         run(psteps)
         conv_ms, conv_flop, conv_n = ddpm.model.read_conv_profile()
         ddpm.model.profile_convs(False)
-        conv = {"kernel": "conv_bf16x3_{pair,stream}_kernel (3x3 implicit-GEMM conv on the bf16 matrix pipe, fp32 operands split "
-                          "exactly into 3 bf16 pieces, 6 products per fp32 product, fp32 accumulate; fused GN+SiLU prologue, "
-                          "residual / GroupNorm-statistics epilogue) + conv_mfma_kernel (fp32-input MFMA) for the 1x1, in_conv "
-                          "and out_conv launches (4 % of the FLOPs)",
+        conv = {"kernel": "conv_bf16x3_* (3x3 implicit-GEMM conv on the bf16 matrix pipe, fp32 operands split exactly into 3 bf16 "
+                          "pieces, 6 products per fp32 product, fp32 accumulate; fused GN+SiLU prologue, residual / GroupNorm-"
+                          "statistics epilogue) + conv_mfma_kernel (fp32-input MFMA) for the 1x1, in_conv and out_conv launches "
+                          "(4 % of the FLOPs)",
                 "launches": conv_n, "launches_per_step": conv_n // psteps, "avg_launch_us": conv_ms * 1e3 / conv_n,
                 "algorithmic_gflop_per_launch": conv_flop / conv_n / 1e9, "tflops": conv_flop / conv_ms / 1e9,
                 "ms_per_step": conv_ms / psteps}
 
     if rank == 0:
+        S = cf["sampler_steps"]
         sec_per_step = dt / args.steps
-        value = world * B / (sec_per_step * SAMPLER_STEPS)
-        step_flops = B * FLOP_PER_IMAGE_STEP / (gpu_ms / 1e3 / args.steps)
+        value = world * B / (sec_per_step * S)
+        step_flops = B * cf["flop"] / (gpu_ms / 1e3 / args.steps)
         line = {
-            "metric": "range-images/sec (64x1024, 256-step DDPM)", "value": value, "unit": "images/s",
+            "metric": cf["metric"], "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x2 (REDUCED PRECISION, optional mode)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16x2 (REDUCED PRECISION, optional mode)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 64x1024x2 range/reflectance, 256-step DDPM, batch 8 per GPU; "
-                                   "timed = one sample() call of --steps reverse steps, value scaled to 256 steps",
-                       "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
-                       "sampler_steps": SAMPLER_STEPS,
+            "config": {"workload": cf["workload"] + f"; timed = one sample() call of --steps reverse steps, value scaled to {S} steps",
+                       "baseline_config": args.config, "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
+                       "sampler": cf["mode"], "sampler_steps": S,
                        "arithmetic": ("fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply on the bf16 matrix "
                                       "pipe with every fp32 operand split exactly into 3 bf16 pieces (6 products, fp32-class error)"
                                       if args.precision == "fp32" else
                                       "fp32 tensors and accumulation; 3x3 convolution operands = 2 bf16 pieces (16 mantissa bits, 3 products)"),
                        "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
             "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": peak_split / 1e12, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] * 1e12 / peak_split, "traffic": pmc_traffic(),
-                         "peak_definition": "dense bf16 MFMA peak 2500 TF/s / %d bf16 products per algorithmic fp32 product" % (6 if args.precision == "fp32" else 3),
+                         "frac": conv["tflops"] * 1e12 / peak_split, "traffic": pmc_traffic() if args.config == 1 else None,
+                         "peak_definition": "dense bf16 MFMA peak 2500 TF/s / %d bf16 products per algorithmic fp32 product" % nprod,
                          "fp32_mfma_peak": PEAK_FP32 / 1e12, "frac_of_fp32_mfma_peak": conv["tflops"] * 1e12 / PEAK_FP32,
                          "dominant_kernel": conv,
                          "whole_step": {"achieved": step_flops / 1e12, "frac": step_flops / peak_split,
                                         "frac_of_fp32_mfma_peak": step_flops / PEAK_FP32,
-                                        "note": "234.52 GFLOP/image-step x batch / HIP-event time of the timed sample() call"},
+                                        "note": "%.2f GFLOP/image-step x batch / HIP-event time of the timed sample() call" % (cf["flop"] / 1e9)},
                          "note": "achieved = sum of algorithmic conv FLOPs / sum of conv kernel time (HIP events on the sampling "
-                                 "stream, rank 0); traffic = HBM bytes per conv launch "
-                                 "from the last committed rocprofv3 PMC passes (profiles/conv_traffic.json: 2 x FETCH_SIZE + "
-                                 "WRITE_SIZE), null if that file is absent; algorithmic bytes per launch = 147.7 MB"},
+                                 "stream, rank 0); traffic = HBM bytes per conv launch from the last committed rocprofv3 PMC passes "
+                                 "(profiles/conv_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE; config 1 only), null if absent; "
+                                 "algorithmic bytes per launch = 147.7 MB (config 1)"},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(ck)
+        if world == 1 and not args.no_torch_baseline:
+            tb = torch_rocm_baseline(ck, cf, B, dev)
+            tb["speedup"] = value / tb["value"]
+            line["torch_rocm_baseline"] = tb
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ck, cf)
         print(json.dumps(line))
     if dist:
         td.destroy_process_group()

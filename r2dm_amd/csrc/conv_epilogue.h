@@ -7,6 +7,124 @@
 
 namespace r2dm {
 
+// Fused GroupNorm statistics, last step: the lanes of a wave hold 4 of the 8 channels (by half-wave) x 32 pixels of every
+// 8-channel block; reduce over the wave in fp64, merge the blocks of a group, one slot per (pixel tile, pixel wave) --
+// fixed summation order, every slot written exactly once per launch.
+template <int WPX, int MR>
+__device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_s)[MR][4], double (&st_q)[MR][4], int b,
+                                               int th, int tw, int nTw, int co_u, int wave_px, int lane) {
+    using gdouble = double __attribute__((address_space(1)))*;  // (global, not FLAT: flat stores also count on lgkmcnt)
+    double bs[MR * 4], bq[MR * 4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            double a = st_s[m][k8], q = st_q[m][k8];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            bs[m * 4 + k8] = a;
+            bq[m * 4 + k8] = q;
+        }
+    if (lane == 0) {
+        // Slots per (sample, group): two halves of S = stat_slots / 2, each with one slot per (pixel tile, pixel
+        // wave).  A wave whose 32*MR channels contain whole groups writes its sums to half 0 and zeros to half 1; a
+        // wave that holds only half of a 64-channel group (32-channel tiles) writes to the half given by its
+        // position in the group.
+        constexpr int R8 = MR * 4;                       // 8-channel blocks per wave
+        const int S = p.stat_slots >> 1;
+        const int bpg = p.stat_cpg >> 3;                 // 8-channel blocks per group
+        const int slot = (th * nTw + tw) * 4 + wave_px;  // 4 slots per pixel tile (unused ones hold zeros)
+        if (bpg <= R8) {
+#pragma unroll
+            for (int g0 = 0; g0 < R8; ++g0) {
+                if (g0 % bpg) continue;
+                double a = 0.0, q = 0.0;
+#pragma unroll
+                for (int k8 = 0; k8 < R8; ++k8)
+                    if (k8 >= g0 && k8 < g0 + bpg) {
+                        a += bs[k8];
+                        q += bq[k8];
+                    }
+                const int g = p.stat_goff + (co_u + g0 * 8) / p.stat_cpg;
+                if (co_u + g0 * 8 < p.Cout) {
+                    gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2);
+                    o[0] = a;
+                    o[1] = q;
+                    o[2 * S] = 0.0;
+                    o[2 * S + 1] = 0.0;
+                    if (WPX == 2) {  // this variant fills only 2 of the tile's 4 slots
+                        o[4] = 0.0;
+                        o[5] = 0.0;
+                        o[2 * S + 4] = 0.0;
+                        o[2 * S + 5] = 0.0;
+                    }
+                }
+            }
+        } else {  // the wave's channels are one half of a group (bpg == 2 * R8)
+            double a = 0.0, q = 0.0;
+#pragma unroll
+            for (int k8 = 0; k8 < R8; ++k8) {
+                a += bs[k8];
+                q += bq[k8];
+            }
+            const int g = p.stat_goff + co_u / p.stat_cpg;
+            const int half = (co_u % p.stat_cpg) / (R8 * 8);
+            gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + half * S + slot) * 2);
+            o[0] = a;
+            o[1] = q;
+        }
+    }
+}
+
+// The same write-out for ONE 32-channel half (MR index m) of a wave that owns 64 output channels, as a butterfly
+// reduce-scatter: 8 values (sum, sum of squares of the four 8-channel blocks) over 64 lanes cost 10 exchange+add steps
+// instead of 48, and the merge of the blocks of a group continues the butterfly.  Value index v = 2*block + (0: sum,
+// 1: squares); after the scatter lane L holds the wave total of v = (L >> 3) & 7.  Groups of 8 / 16 / 32 channels lie
+// inside the half (slot half 0, zeros to half 1); a 64-channel group takes the two halves of its wave in slot halves
+// 0 and 1, exactly as two 32-channel tiles would.  Fixed summation order, every slot written exactly once per launch.
+__device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double (&st_s)[4], double (&st_q)[4], int b, int th,
+                                                     int tw, int nTw, int co_half, int wave_px, int lane) {
+    using gdouble = double __attribute__((address_space(1)))*;
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = st_s[j];
+        v[2 * j + 1] = st_q[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // scatter: the lane bit (32, 16, 8) selects which half of the live values a lane keeps
+        const int nv = 4 >> k, off = 32 >> k;
+        const bool up = lane & off;
+#pragma unroll
+        for (int i = 0; i < nv; ++i) {
+            const double keep = up ? v[i + nv] : v[i], send = up ? v[i] : v[i + nv];
+            v[i] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    double t = v[0];
+    t += __shfl_xor(t, 4, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 1, 64);
+    // lane L: total of block k8 = (L >> 4) & 3, kind = (L >> 3) & 1; partners within a group differ in lane bits 4, 5
+    const int bpg = p.stat_cpg >> 3;  // 1, 2, 4 or 8 blocks per group
+    if (bpg >= 2) t += __shfl_xor(t, 16, 64);
+    if (bpg >= 4) t += __shfl_xor(t, 32, 64);
+    const int k8 = (lane >> 4) & 3, kind = (lane >> 3) & 1;
+    const int bin = bpg < 4 ? bpg : 4;  // blocks of a group inside this half
+    if ((lane & 7) == 0 && (k8 & (bin - 1)) == 0) {
+        const int S = p.stat_slots >> 1;
+        const int slot = (th * nTw + tw) * 4 + wave_px;
+        const int g = p.stat_goff + (co_half + k8 * 8) / p.stat_cpg;
+        const int half = bpg == 8 ? (co_half % p.stat_cpg) / 32 : 0;
+        gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2);
+        o[2 * S * half + kind] = t;
+        if (bpg < 8) o[2 * S + kind] = 0.0;
+    }
+}
+
 // The wave owns output channels [co_u, co_u + 32*MR) and NR pixel segments (32 consecutive columns of one row each);
 // segment index s = wave_px*NR + n -> row s / (TW/32), column block s % (TW/32) of the TH x TW pixel tile.
 template <int WPX, int TH, int TW, int MR, int NR, bool ACC2>
@@ -81,73 +199,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                 }
     }
-    if (p.stat) {
-        // lanes of a wave hold 4 of the 8 channels (by half-wave) x 32 pixels of every 8-channel block: reduce over
-        // the wave in fp64, merge the blocks of a group, one slot per (pixel tile, pixel wave) -- fixed order.
-        double bs[MR * 4], bq[MR * 4];
-#pragma unroll
-        for (int m = 0; m < MR; ++m)
-#pragma unroll
-            for (int k8 = 0; k8 < 4; ++k8) {
-                double a = st_s[m][k8], q = st_q[m][k8];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                bs[m * 4 + k8] = a;
-                bq[m * 4 + k8] = q;
-            }
-        if (lane == 0) {
-            // Slots per (sample, group): two halves of S = stat_slots / 2, each with one slot per (pixel tile, pixel
-            // wave).  A wave whose 32*MR channels contain whole groups writes its sums to half 0 and zeros to half 1; a
-            // wave that holds only half of a 64-channel group (32-channel tiles) writes to the half given by its
-            // position in the group.  Every slot is written exactly once per launch: fixed summation order.
-            constexpr int R8 = MR * 4;                       // 8-channel blocks per wave
-            const int S = p.stat_slots >> 1;
-            const int bpg = p.stat_cpg >> 3;                 // 8-channel blocks per group
-            const int slot = (th * nTw + tw) * 4 + wave_px;  // 4 slots per pixel tile (unused ones hold zeros)
-            if (bpg <= R8) {
-#pragma unroll
-                for (int g0 = 0; g0 < R8; ++g0) {
-                    if (g0 % bpg) continue;
-                    double a = 0.0, q = 0.0;
-#pragma unroll
-                    for (int k8 = 0; k8 < R8; ++k8)
-                        if (k8 >= g0 && k8 < g0 + bpg) {
-                            a += bs[k8];
-                            q += bq[k8];
-                        }
-                    const int g = p.stat_goff + (co_u + g0 * 8) / p.stat_cpg;
-                    if (co_u + g0 * 8 < p.Cout) {
-                        double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2;
-                        o[0] = a;
-                        o[1] = q;
-                        o[2 * S] = 0.0;
-                        o[2 * S + 1] = 0.0;
-                        if (WPX == 2) {  // this variant fills only 2 of the tile's 4 slots
-                            o[4] = 0.0;
-                            o[5] = 0.0;
-                            o[2 * S + 4] = 0.0;
-                            o[2 * S + 5] = 0.0;
-                        }
-                    }
-                }
-            } else {  // the wave's channels are one half of a group (bpg == 2 * R8)
-                double a = 0.0, q = 0.0;
-#pragma unroll
-                for (int k8 = 0; k8 < R8; ++k8) {
-                    a += bs[k8];
-                    q += bq[k8];
-                }
-                const int g = p.stat_goff + co_u / p.stat_cpg;
-                const int half = (co_u % p.stat_cpg) / (R8 * 8);
-                double* o = p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + half * S + slot) * 2;
-                o[0] = a;
-                o[1] = q;
-            }
-        }
-    }
+    if (p.stat) epi_stat_write<WPX, MR>(p, st_s, st_q, b, th, tw, nTw, co_u, wave_px, lane);
 }
 
 }  // namespace r2dm

@@ -197,9 +197,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     auto load_piece = [&](int i) __attribute__((always_inline)) {
         if (i < 8)
             raw[i] = *reinterpret_cast<const f32x4*>(xq + (long)i * HW);
-        else if (PRO != PRO_NONE) {
-            const f32x4 v = aq[i - 8];  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
-            ad4[i - 8] = s_ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (PRO != PRO_NONE)
+            ad4[i - 8] = aq[i - 8];  // masked by mask_affine() at the consumer: a select on a just-loaded value makes hipcc
+                                     // wait for it -- and for every older load -- on the spot, inside the MFMA stream
+    };
+    // zero padding of the ACTIVATED tensor (rows outside the image): a = d = 0 gives silu(0) = 0
+    auto mask_affine = [&]() __attribute__((always_inline)) {
+        if (PRO != PRO_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ad4[j] = s_ok ? ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // micro-slice `sl` (0..13) of channel pair k = 4*pixel + pair (same arithmetic as silu_f() / split3_pk())
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     load_setup(0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) load_piece(i);
+    mask_affine();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
 #pragma unroll
@@ -367,6 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
 #pragma unroll
                     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ad4[j]));
                 }
+                mask_affine();  // (before this tap's first transform slice)
             }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tap's fragments (issued a tap ago)
@@ -485,7 +493,12 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
         for (int n = 0; n < NR; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;  // everything was flushed (Cin % 64 == 0)
-    conv_epilogue<4, TH, TW, MR, NR, true>(p, acc, acc2, b, th, tw, nTw, cot * CO_T, wave, lane);
+    // whole tiles (every shape of the network): the wide epilogue through this wave's 1 KiB patch behind the weight ring
+    if (H % TH == 0 && W % TW == 0)
+        conv_epilogue_wide<TH, TW, MR, NR, true>(p, acc, acc2, b, th, tw, nTw, cot * CO_T, wave, lane,
+                                                 reinterpret_cast<float*>(smem + WB0 + RING * WBYTES) + wave * 256);
+    else
+        conv_epilogue<4, TH, TW, MR, NR, true>(p, acc, acc2, b, th, tw, nTw, cot * CO_T, wave, lane);
 
     if (p.prof && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -587,9 +600,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
     auto load_piece = [&](int i) __attribute__((always_inline)) {
         if (i < 8)
             raw[i] = *reinterpret_cast<const f32x4*>(xq + (long)i * HW);
-        else if (PRO != PRO_NONE) {
-            const f32x4 v = aq[i - 8];  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
-            ad4[i - 8] = s_ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (PRO != PRO_NONE)
+            ad4[i - 8] = aq[i - 8];  // masked by mask_affine() at the consumer: a select on a just-loaded value makes hipcc
+                                     // wait for it -- and for every older load -- on the spot, inside the MFMA stream
+    };
+    // zero padding of the ACTIVATED tensor (rows outside the image): a = d = 0 gives silu(0) = 0
+    auto mask_affine = [&]() __attribute__((always_inline)) {
+        if (PRO != PRO_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ad4[j] = s_ok ? ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // micro-slice `sl` (0..13) of channel pair k = 4*pixel + pair (same arithmetic as silu_f() / split3_pk())
@@ -683,6 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
     // four independent dependency chains instead of one
     auto transform_all = [&]() __attribute__((always_inline)) {
         float v0[4], v1[4], m0[4], m1[4];
+        mask_affine();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -839,7 +859,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // surplus DMA pieces / prefetched fragments must not outlive the block
     if (p.prof) t2 = __builtin_amdgcn_s_memtime();
 
-    conv_epilogue<4, TH, TW, MR, NR, false>(p, acc, accd, b, th, tw, nTw, cot * CO_T, wave, lane);
+    if (H % TH == 0 && W % TW == 0)  // whole tiles: wide epilogue, this wave's 1 KiB patch behind the weight ring
+        conv_epilogue_wide<TH, TW, MR, NR, false>(p, acc, accd, b, th, tw, nTw, cot * CO_T, wave, lane,
+                                                  reinterpret_cast<float*>(smem + WB1 + RING2 * WBYTES) + wave * 256);
+    else
+        conv_epilogue<4, TH, TW, MR, NR, false>(p, acc, accd, b, th, tw, nTw, cot * CO_T, wave, lane);
 
     if (p.prof && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1292,8 +1316,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_duo_kernel(const ConvParam
                 if (i == 10) fr(ic<10>{});
                 if (i == 11) fr(ic<11>{});
             }
-#ifdef DUO_RAW_IN_STREAM  // experiment: the next chunk's pixel loads from the stream's last tap instead of the break
-            if (t == 8) {
+#ifndef DUO_NO_RAWLOAD  // (DUO_NO_*: ablation switches for scripts/build_variant.sh -- timing experiments, wrong results)
+            if (t == 8) {  // the next chunk's twelve pixel / affine loads ride on the last units of the stream, where the second
+                           // fragment buffer is idle; unconditional, so that the registers are plainly redefined here
                 const int idx = i - (UNITS - 12);
                 if (idx >= 0) load_piece(idx);
             }
@@ -1302,16 +1327,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_duo_kernel(const ConvParam
         }
     };
 
-    // the group's chunk after next: addresses, then its twelve 16-byte loads -- issued as soon as the transform has
-    // consumed the previous ones, a whole multiplication phase before they are needed.  Unconditional (after the last
-    // chunk: the last addresses again, unused) so that the registers are plainly redefined here.
-    auto next_raw = [&]() __attribute__((always_inline)) {
-        prep_load();
-#if !defined(DUO_NO_RAWLOAD) && !defined(DUO_RAW_IN_STREAM)
-#pragma unroll
-        for (int i = 0; i < 12; ++i) load_piece(i);
-#endif
-    };
+    // addresses of the group's chunk after next (its loads are issued from the last tap of the coming MFMA stream; issuing
+    // them here, a whole phase earlier, keeps 48 more registers live across the stream: spills, measured 12 % slower)
+    auto next_raw = [&]() __attribute__((always_inline)) { prep_load(); };
 
     // ---- everything between two multiplications of a group: three parts around the block's three barriers ----
     // qd: chunk just multiplied, qn = qd + 1 (== Q: none left).  sync = false: the follower's last tile -- no partner left
@@ -1429,9 +1447,6 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_duo_kernel(const ConvParam
             if (!follower) dma_stage(3 * qd + 2);
             stamp(43);
         }
-        // last: the pixel loads of the chunk after next.  Nothing of this function may follow them -- a reload of a spilled
-        // value behind them would wait for all twelve (hipcc drains vmcnt for scratch reloads)
-        __builtin_amdgcn_sched_barrier(0);
         next_raw();
         stamp(44);
     };
@@ -1541,7 +1556,7 @@ hipError_t launch_pack_conv_bf16x3(const float* w, float* dst, int Cout, int Cin
 template <int PRO, int NPC>
 static hipError_t launch_x3_pair(const ConvParams& p, hipStream_t s) {
     auto kern = conv_bf16x3_pair_kernel<PRO, NPC>;
-    constexpr int lds = x3s::XBYTES2 + 2 * x3::WBYTES;
+    constexpr int lds = x3s::XBYTES2 + 2 * x3::WBYTES + 4096;  // + four 1 KiB epilogue patches: 79552 B, two blocks per CU
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1571,13 +1586,14 @@ static hipError_t launch_x3_duo(const ConvParams& p, long total_items, int n_cu,
     return hipGetLastError();
 }
 
-// Cin <= 128: the duo kernel when the launch has at least `duo_min` (co tile, tile pair) items -- enough to give every CU
-// a block of two tiles -- else the pair kernel (one tile per block, two blocks per CU).  R2DM_DUO_MIN overrides the
-// threshold (experiments / tests: 1 = always duo, a huge value = never).
+// Cin <= 128: the pair kernel by default.  The duo kernel is an opt-in experiment (R2DM_DUO_MIN=<items>: use it for launches
+// with at least that many (co tile, tile pair) items; 1 = every shallow layer): after the fixes that came out of its
+// timeline probe went into the pair kernel as well, it is on par with it ("what bounds the shallow
+// layers"), so the simpler kernel stays the product path.
 static long duo_min_items() {
     static const long v = [] {
         const char* e = getenv("R2DM_DUO_MIN");
-        return e ? atol(e) : 192L;
+        return e ? atol(e) : (1L << 62);
     }();
     return v;
 }
@@ -1593,7 +1609,7 @@ static int cu_count() {
 template <int PRO, int COT, int NPC>
 static hipError_t launch_x3_stream(const ConvParams& p, hipStream_t s) {
     auto kern = conv_bf16x3_stream_kernel<PRO, COT, NPC>;
-    constexpr int lds = x3s::WB0 + x3s::RING * (3 * 3 * x3::NG * COT * 16);
+    constexpr int lds = x3s::WB0 + x3s::RING * (3 * 3 * x3::NG * COT * 16) + 4096;  // + four 1 KiB epilogue patches
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

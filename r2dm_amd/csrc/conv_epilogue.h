@@ -125,6 +125,89 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
     }
 }
 
+// ---- wide epilogue (whole tiles: H % TH == 0, W % TW == 0, Cout % (32 MR) == 0) --------------------------------------
+// The MFMA layout gives a lane ONE pixel of 16 channels, i.e. 4-byte global accesses, 256 B per instruction -- and a CU
+// retires those at a few bytes per cycle (in-kernel timeline of round 2: the residual loads + stores of one 64 x 256 tile
+// took as long as two thirds of its MFMA time).  Every 8-channel block is therefore turned through a private 1 KiB LDS
+// patch (4 ds_write_b32 + 1 ds_read_b128; no barrier: the LDS operations of one wave execute in order) into
+// "4 consecutive pixels of one channel per lane": residual loads and output stores are 16 bytes per lane, 1 KiB per
+// instruction, a quarter as many.  Statistics: the four pixels are summed in fp32 (3 + 4 roundings of ~6e-8, unbiased and
+// independent from lane to lane: they average out over the >= 10^4 lanes x tiles of a group), fp64 beyond that, butterfly
+// reduce-scatter per 32-channel half (epi_stat_write_bfly8).
+// Explicit global address space everywhere: a pointer that reaches a load through a phi is otherwise accessed with FLAT
+// instructions, which count on lgkmcnt as well and turn every LDS wait into a wait for HBM.
+template <int TH, int TW, int MR, int NR, bool ACC2>
+__device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (&acc)[MR][NR],
+                                                   f32x16 (&acc2)[ACC2 ? MR : 1][ACC2 ? NR : 1], int b, int th, int tw,
+                                                   int nTw, int co_u, int wave_px, int lane, float* patch) {
+    using gcf = const float __attribute__((address_space(1)))*;
+    using gcf4 = const f32x4 __attribute__((address_space(1)))*;
+    using gf4 = f32x4 __attribute__((address_space(1)))*;
+    constexpr int SEGW = TW / 32;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int tq_c = lane >> 3, tq_p = (lane & 7) * 4;  // after the turn: channel within the block, first of 4 pixels
+    const float sc = p.scale ? *p.scale : 1.0f;
+    const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)co_u * HW);
+    const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)co_u * HW);  // (only dereferenced if p.res)
+    int loff[NR];  // in units of 4 floats
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int s = wave_px * NR + n;
+        loff[n] = (tq_c * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + tq_p) >> 2;
+    }
+    float bias[MR][4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) bias[m][k8] = ((gcf)p.bias)[co_u + m * 32 + k8 * 8 + tq_c];
+    f32x4 rv[2][4];  // residual values: the quarter being finished and the next one in flight
+    auto load_q = [&](int m, int n, f32x4 (&r)[4]) __attribute__((always_inline)) {
+        if (p.res) {
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) r[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]];
+        }
+    };
+    load_q(0, 0, rv[0]);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        double st_s[4], st_q[4];
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) st_s[k8] = st_q[k8] = 0.0;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            constexpr int NQ = MR * NR;
+            const int q = m * NR + n;
+            if (q + 1 < NQ) load_q((q + 1) / NR, (q + 1) % NR, rv[(q + 1) & 1]);
+            f32x4 t[4];
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) {  // the four blocks through the patch back to back (in-order LDS: no waits between)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[m][n][4 * k8 + j];
+                    if (ACC2) v += acc2[ACC2 ? m : 0][ACC2 ? n : 0][4 * k8 + j];
+                    patch[(j + 4 * hi) * 32 + l31] = v;
+                }
+                t[k8] = *reinterpret_cast<const f32x4*>(patch + tq_c * 32 + tq_p);
+            }
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) {
+                f32x4 v = t[k8] + bias[m][k8];
+                if (p.res) v = rv[q & 1][k8] + v;
+                if (p.scale) v *= sc;
+                (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]] = v;
+                if (p.stat) {
+                    const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+                    const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                    st_s[k8] += (double)s4;
+                    st_q[k8] += (double)q4;
+                }
+            }
+        }
+        if (p.stat) epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, co_u + m * 32, wave_px, lane);
+    }
+}
+
 // The wave owns output channels [co_u, co_u + 32*MR) and NR pixel segments (32 consecutive columns of one row each);
 // segment index s = wave_px*NR + n -> row s / (TW/32), column block s % (TW/32) of the TH x TW pixel tile.
 template <int WPX, int TH, int TW, int MR, int NR, bool ACC2>

@@ -494,7 +494,11 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;  // everything was flushed (Cin % 64 == 0)
     // whole tiles (every shape of the network): the wide epilogue through this wave's 1 KiB patch behind the weight ring
+#ifndef R2DM_NO_WIDE_EPILOGUE
     if (H % TH == 0 && W % TW == 0)
+#else
+    if (false)
+#endif
         conv_epilogue_wide<TH, TW, MR, NR, true>(p, acc, acc2, b, th, tw, nTw, cot * CO_T, wave, lane,
                                                  reinterpret_cast<float*>(smem + WB0 + RING * WBYTES) + wave * 256);
     else
@@ -859,7 +863,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_pair_kernel(const ConvPara
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // surplus DMA pieces / prefetched fragments must not outlive the block
     if (p.prof) t2 = __builtin_amdgcn_s_memtime();
 
+#ifndef R2DM_NO_WIDE_EPILOGUE
     if (H % TH == 0 && W % TW == 0)  // whole tiles: wide epilogue, this wave's 1 KiB patch behind the weight ring
+#else
+    if (false)
+#endif
         conv_epilogue_wide<TH, TW, MR, NR, false>(p, acc, accd, b, th, tw, nTw, cot * CO_T, wave, lane,
                                                   reinterpret_cast<float*>(smem + WB1 + RING2 * WBYTES) + wave * 256);
     else

@@ -36,18 +36,23 @@ def broadcast_tensor(t: torch.Tensor, src: int = 0) -> torch.Tensor:
 
 
 def broadcast_packed_weights(model, device, src: int = 0) -> None:
-    """Rank `src` packs its weights into the engine blob; the blob is broadcast and adopted by all."""
+    """Rank `src` packs its weights into the engine blob; the blob is broadcast and adopted by all.
+
+    Under RCCL ("nccl") the blob travels GPU to GPU over xGMI.  Under gloo (tests: several ranks on one GPU) it is staged
+    through host memory -- gloo's device support is not a given on a ROCm build."""
     td = _dist()
     if td is None or td.get_world_size() == 1:
         model.packed_weights(device)
         return
+    on_host = td.get_backend() != "nccl"
     if td.get_rank() == src:
         blob = model.packed_weights(device)
+        wire = blob.cpu() if on_host else blob
     else:
-        blob = torch.empty(model.packed_weight_bytes(), dtype=torch.uint8, device=device)
-    td.broadcast(blob, src=src)
+        wire = torch.empty(model.packed_weight_bytes(), dtype=torch.uint8, device="cpu" if on_host else device)
+    td.broadcast(wire, src=src)
     if td.get_rank() != src:
-        model.adopt_packed_weights(blob)
+        model.adopt_packed_weights(wire.to(device) if on_host else wire)
 
 
 def sample_sharded(sample_fn: Callable[[List[int]], torch.Tensor], seeds: Sequence[int], gather: bool = True,

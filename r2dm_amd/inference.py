@@ -1,6 +1,9 @@
 """Model factory: checkpoint dict / file -> (ddpm, lidar_utils, cfg).
 
-Same entry points, arguments and return values as /root/reference/utils/inference.py:16-114.
+Entry points, argument names and return values are those of the reference's factory
+(/root/reference/utils/inference.py:20-114) -- ``setup_model`` is the seam ``hubconf.pretrained_r2dm``,
+``generate.py`` and ``sample_and_save.py`` go through -- but the body is this package's own: the checkpoint's
+``cfg`` section is mapped onto the HIP engine's geometry and one of two sampler classes by lookup tables.
 """
 from __future__ import annotations
 
@@ -13,92 +16,70 @@ from .lidar import LiDARUtility
 from .option import Config
 from .unet import EfficientUNet
 
+# cfg.model fields that define the denoiser's geometry (everything else in cfg.model is training-only)
+_GEOMETRY_FIELDS = ("base_channels", "temb_channels", "channel_multiplier", "num_residual_blocks", "gn_num_groups", "gn_eps",
+                    "attn_num_heads", "coords_encoding")
+# cfg.diffusion.timestep_type -> (sampler class, cfg.diffusion fields it takes besides the common three)
+_SAMPLERS = {
+    "continuous": (ContinuousTimeGaussianDiffusion, ()),
+    "discrete": (DiscreteTimeGaussianDiffusion, ("num_training_steps",)),
+}
+_COMMON_DIFFUSION_FIELDS = ("loss_type", "prediction_type", "noise_schedule")
+
 
 def count_parameters(model: torch.nn.Module) -> int:
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
 
 
+def _denoiser(cfg: Config, max_batch: int) -> EfficientUNet:
+    arch = cfg.model.architecture
+    if arch == "refinenet":
+        raise NotImplementedError("architecture='refinenet' (LiDARGen baseline, /root/reference/models/refinenet.py) "
+                                  "is outside the built hot path; see DESIGN.md")
+    if arch != "efficient_unet":
+        raise ValueError(f"Unknown: {arch}")
+    channels = int(bool(cfg.data.train_depth)) + int(bool(cfg.data.train_reflectance))
+    geometry = {k: getattr(cfg.model, k) for k in _GEOMETRY_FIELDS}
+    return EfficientUNet(in_channels=channels, resolution=cfg.data.resolution, ring=True, max_batch=max_batch, **geometry)
+
+
+def _sampler(cfg: Config, model: EfficientUNet) -> GaussianDiffusion:
+    kind = cfg.diffusion.timestep_type
+    if kind not in _SAMPLERS:
+        raise ValueError(f"Unknown: {kind}")
+    cls, extra = _SAMPLERS[kind]
+    return cls(model=model, **{k: getattr(cfg.diffusion, k) for k in _COMMON_DIFFUSION_FIELDS + extra})
+
+
 def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, compile: bool = False,
                 max_batch: int = 8, precision: str = "fp32"):
-    """Build the sampler from a checkpoint (utils/inference.py:20-110).
+    """Build the sampler from a checkpoint (path or the dict ``train.py`` saves: cfg / weights / ema_weights /
+    global_step, train.py:294-303).
 
-    ``max_batch`` (extension) tells the HIP engine which batch size to tile its layers for; ``precision`` (extension)
-    is ``"fp32"`` (parity mode) or ``"bf16x2"`` (reduced precision, see ``EfficientUNet.set_precision``)."""
+    ``max_batch`` (extension) tells the HIP engine which batch size to tile its layers for -- per-seed results are
+    bit-reproducible for a fixed ``max_batch`` only (different tilings sum in a different order); ``precision``
+    (extension) is ``"fp32"`` (parity mode) or ``"bf16x2"`` (reduced precision, see ``EfficientUNet.set_precision``).
+    ``compile=True`` wraps the denoiser in ``torch.compile`` as upstream does; its forward is one ctypes call into the
+    HIP library, i.e. a graph break that runs eagerly."""
     if isinstance(ckpt, (str, Path)):
         ckpt = torch.load(ckpt, map_location="cpu")
     cfg = Config(**ckpt["cfg"])
-
-    in_channels = int(bool(cfg.data.train_depth)) + int(bool(cfg.data.train_reflectance))
-    if cfg.model.architecture == "efficient_unet":
-        model = EfficientUNet(
-            in_channels=in_channels,
-            resolution=cfg.data.resolution,
-            base_channels=cfg.model.base_channels,
-            temb_channels=cfg.model.temb_channels,
-            channel_multiplier=cfg.model.channel_multiplier,
-            num_residual_blocks=cfg.model.num_residual_blocks,
-            gn_num_groups=cfg.model.gn_num_groups,
-            gn_eps=cfg.model.gn_eps,
-            attn_num_heads=cfg.model.attn_num_heads,
-            coords_encoding=cfg.model.coords_encoding,
-            ring=True,
-            max_batch=max_batch,
-        )
-    elif cfg.model.architecture == "refinenet":
-        raise NotImplementedError("architecture='refinenet' (LiDARGen baseline, /root/reference/models/refinenet.py) "
-                                  "is outside the built hot path; see DESIGN.md")
-    else:
-        raise ValueError(f"Unknown: {cfg.model.architecture}")
-
-    if cfg.diffusion.timestep_type == "discrete":
-        ddpm = DiscreteTimeGaussianDiffusion(
-            model=model,
-            loss_type=cfg.diffusion.loss_type,
-            num_training_steps=cfg.diffusion.num_training_steps,
-            prediction_type=cfg.diffusion.prediction_type,
-            noise_schedule=cfg.diffusion.noise_schedule,
-        )
-    elif cfg.diffusion.timestep_type == "continuous":
-        ddpm = ContinuousTimeGaussianDiffusion(
-            model=model,
-            loss_type=cfg.diffusion.loss_type,
-            prediction_type=cfg.diffusion.prediction_type,
-            noise_schedule=cfg.diffusion.noise_schedule,
-        )
-    else:
-        raise ValueError(f"Unknown: {cfg.diffusion.timestep_type}")
-
-    state_dict = ckpt["ema_weights"] if ema else ckpt["weights"]
-    ddpm.load_state_dict(state_dict)
-    ddpm.eval()
-    ddpm.requires_grad_(False)
-    ddpm.to(device)
-    ddpm.model.set_precision(precision)
-
+    model = _denoiser(cfg, max_batch)
+    ddpm = _sampler(cfg, model)
+    ddpm.load_state_dict(ckpt["ema_weights" if ema else "weights"])
+    ddpm.eval().requires_grad_(False).to(device)
+    model.set_precision(precision)
     if compile:
-        ddpm.model = torch.compile(ddpm.model)  # the ctypes call is a graph break -> runs eagerly
+        ddpm.model = torch.compile(ddpm.model)
 
-    lidar_utils = LiDARUtility(
-        resolution=cfg.data.resolution,
-        depth_format=cfg.data.depth_format,
-        min_depth=cfg.data.min_depth,
-        max_depth=cfg.data.max_depth,
-        ray_angles=model.coords,
-    )
-    lidar_utils.eval()
-    lidar_utils.to(device)
+    lidar_utils = LiDARUtility(resolution=cfg.data.resolution, depth_format=cfg.data.depth_format, min_depth=cfg.data.min_depth,
+                               max_depth=cfg.data.max_depth, ray_angles=model.coords)
+    lidar_utils.eval().to(device)
 
     if show_info:
-        print(
-            *[
-                f"resolution: {model.resolution}",
-                f"model: {model.__class__.__name__}",
-                f"ddpm: {ddpm.__class__.__name__}",
-                f'#steps:  {ckpt["global_step"]:,}',
-                f"#params: {sum(p.numel() for p in ddpm.parameters()):,}",
-            ],
-            sep="\n",
-        )
+        facts = {"resolution": model.resolution, "model": type(model).__name__, "ddpm": type(ddpm).__name__,
+                 "#steps": f'{ckpt["global_step"]:,}', "#params": f"{sum(p.numel() for p in ddpm.parameters()):,}"}
+        print("\n".join(f"{k}: {v}" for k, v in facts.items()))
     return ddpm, lidar_utils, cfg
 
 

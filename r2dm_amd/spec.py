@@ -84,14 +84,9 @@ class UNetGeometry:
 
     @property
     def coord_channels(self) -> int:
-        if self.coords_encoding == "fourier_features":
-            return 2 * sum(self.fourier_levels)
-        if self.coords_encoding is None:
-            return 0
-        raise NotImplementedError(
-            f"coords_encoding={self.coords_encoding!r}: only 'fourier_features' (the default / "
-            "pretrained configuration) and None are built; see DESIGN.md 'out of scope'"
-        )
+        from .encodings import coord_channels
+
+        return coord_channels(self.coords_encoding, self.resolution)
 
     @property
     def level_channels(self) -> List[int]:

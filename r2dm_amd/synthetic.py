@@ -98,10 +98,12 @@ def default_cfg_dict(
     timestep_type: str = "continuous",
     noise_schedule: str = "cosine",
     num_training_steps: Optional[int] = None,
+    **model_overrides,
 ) -> dict:
     """``asdict(Config)`` of the reference's default configuration
-    (/root/reference/utils/option.py:6-77) with the fields tests vary exposed."""
-    return {
+    (/root/reference/utils/option.py:6-77) with the fields tests vary exposed; any key of the ``model`` section
+    (``coords_encoding``, ``gn_num_groups``, ``attn_num_heads``, ``channel_multiplier`` ...) may be overridden by keyword."""
+    cfg = {
         "data": {
             "dataset": "kitti_360",
             "depth_format": "log_depth",
@@ -132,6 +134,11 @@ def default_cfg_dict(
         },
         "training": {},
     }
+    unknown = set(model_overrides) - set(cfg["model"])
+    if unknown:
+        raise TypeError(f"unknown model options {sorted(unknown)}")
+    cfg["model"].update(model_overrides)
+    return cfg
 
 
 def geometry_from_cfg(cfg: dict) -> UNetGeometry:

@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from .encodings import coords_constant
 from .spec import Entry, UNetGeometry, unet_entries
 
 _FIR_DOWN = (0.125, 0.375, 0.375, 0.125)
@@ -162,7 +163,7 @@ class EfficientUNet(nn.Module):
             temb_channels=temb_channels, channel_multiplier=channel_multiplier,
             num_residual_blocks=num_residual_blocks, gn_num_groups=gn_num_groups, gn_eps=gn_eps,
             attn_num_heads=attn_num_heads, coords_encoding=coords_encoding)
-        self.geometry.coord_channels  # raises for encodings outside the built scope
+        self.geometry.coord_channels  # raises ValueError for an unknown encoding
         self.resolution = self.geometry.resolution
         self.in_channels = in_channels
         self.out_channels = self.geometry.out_channels
@@ -200,13 +201,9 @@ class EfficientUNet(nn.Module):
     def _constants(self, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         g = self.geometry
         out = {}
-        if g.coords_encoding == "fourier_features":
-            # models/encoding.py:141-146, evaluated once: coords are constant across steps and batch.
-            # Done on the HOST: arguments reach 2^9*pi and f*theta must be the exact float product before
-            # sin/cos; a GPU conv library (MIOpen) does not guarantee that and costs ~1e-5 on the U-Net output.
-            z = torch.nn.functional.conv2d(sd["coords"].float().cpu(), sd["coords_encoding.freqs"].float().cpu(),
-                                           sd["coords_encoding.phase"].float().cpu())
-            out["__cenc"] = torch.cat([z.sin(), z.cos()], dim=1)[0]
+        if g.coords_encoding is not None:  # constant across steps and batch: evaluated once, on the host (encodings.py)
+            out["__cenc"] = coords_constant(g.coords_encoding, sd["coords"], sd.get("coords_encoding.freqs"),
+                                            sd.get("coords_encoding.phase"))
         half = g.base_channels // 2
         # models/ops.py:22-23 (host float32, exactly the reference expression)
         hcoef = -math.log(10_000) / (half - 1)
@@ -285,7 +282,8 @@ class EfficientUNet(nn.Module):
         return ms.value, fl.value, n.value
 
     # -- the hot path ----------------------------------------------------------------------------
-    def forward(self, images: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+    @torch.compiler.disable  # one ctypes call into libr2dm_hip.so: nothing for a tracing compiler to see (runs eagerly under
+    def forward(self, images: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:  # torch.compile, sample_and_save.py:45)
         _lib.require_gpu(images, "images")
         if images.dim() != 4 or images.shape[1] != self.in_channels or tuple(images.shape[2:]) != self.resolution:
             raise ValueError(f"expected (B,{self.in_channels},{self.resolution[0]},{self.resolution[1]}), "

@@ -138,8 +138,10 @@ def test_sample_golden(golden, mode):
     1e-5..1.4e-4 against fp64 arithmetic depending on the noise draw), and at this 8192-pixel size even the RMS of
     step 1 is set by 2-3 such pixels: two HIP builds with the SAME U-Net accuracy (rms 2.7e-7 vs 2.8e-7 against fp64,
     scripts/diag_unet.py) gave 0.9e-6 and 2.1e-6 here.  The robust statements are
-      * the 99th percentile of |error vs fp64 truth| within 6x of the reference's (both ~1e-7; oneDNN's blocked
-        fp32 accumulation is unusually accurate), and RMS(hip - reference) < 1e-5, RMS vs truth < 5e-6 at every step;
+      * the 99th percentile of |error vs fp64 truth| within 2.5x of the reference's (measured 0.6x .. 1.8x; the U-Net's
+        convolutions carry ~1.7x the accumulation roundoff of oneDNN's blocked fp32 sums -- per-layer budget in
+        profiles/r02a_error_budget_default.txt; the fused SiLU approximations are NOT the cause: ablation there),
+        and RMS(hip - reference) < 1e-5, RMS vs truth < 3.5e-6 at every step (measured <= 1.6e-6);
       * max|hip - reference| < 3e-4 (DDPM; errors contract) / 1.5e-3 (DDIM: no fresh noise, errors persist);
       * the final DDPM sample -- what BASELINE.json's "per-pixel delta < 1e-4" is about -- within 1e-4."""
     g = golden(f"sample_{mode}")
@@ -157,8 +159,8 @@ def test_sample_golden(golden, mode):
         print("   " + "  ".join(f"{v:.2e}" for v in r))
     for i, (mx, r_hr, r_ht, r_rt, q_ht, q_rt) in enumerate(rows):
         assert r_hr < (1e-5 if mode == "ddpm" else 2e-5), (i, rows[i])  # (DDIM carries the step-1 lottery to the end)
-        assert q_ht <= max(6 * q_rt, 1e-6), (i, rows[i])
-        assert r_ht <= (5e-6 if mode == "ddpm" else 2e-5), (i, rows[i])  # (DDIM: no fresh noise, errors persist)
+        assert q_ht <= max(2.5 * q_rt, 1e-6), (i, rows[i])
+        assert r_ht <= (3.5e-6 if mode == "ddpm" else 2e-5), (i, rows[i])  # (DDIM: no fresh noise, errors persist; measured 8.4e-6)
         assert mx < (3e-4 if mode == "ddpm" else 1.5e-3), (i, rows[i])
     if mode == "ddpm":
         assert rows[-1][0] < 1e-4
@@ -215,10 +217,11 @@ def test_sample_full_size_vs_oracle():
     for r in rows:
         print("   " + "  ".join(f"{v:.2e}" for v in r))
     # 4 coarse steps of an UNTRAINED (high-gain) network; see test_sample_golden for why the tail pixels are excluded
+    # measured: q99 1.0x .. 1.9x of the reference's, rms(hip - fp64) 5.4 .. 6.2e-6 (reference 1.8 .. 2.6e-6), max 1.9e-3
     for mx, r_hr, r_ht, r_rt, q_ht, q_rt in rows:
-        assert r_hr < 2e-5, rows
-        assert q_ht <= max(6 * q_rt, 1e-6), rows
-        assert r_ht <= max(6 * r_rt, 2e-5), rows
+        assert r_hr < 1.5e-5, rows
+        assert q_ht <= max(2.5 * q_rt, 1e-6), rows
+        assert r_ht <= max(4 * r_rt, 1.2e-5), rows
         assert mx < 4e-3, rows
 
 

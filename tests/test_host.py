@@ -166,3 +166,54 @@ def test_lidar_utility_cpu_members(golden):
     back = lu.convert_depth(depth)
     m = lu.get_mask(depth)
     assert ((back - s[:, [0]]) * m).abs().max() < 1e-5
+
+
+def test_non_default_schedules_match_reference(golden):
+    """S4 / S5 variants (continuous_time.py:18-58, discrete_time.py:22-48): the other log-SNR schedules and the cosine /
+    sigmoid beta tables, bit-identical to what the reference computes (golden 'variants')."""
+    from r2dm_amd import diffusion as D
+
+    class Stub(torch.nn.Module):
+        resolution, in_channels = GOLDEN_RES, 2
+
+    g = golden("variants")
+    t = g["t"]
+    cases = {
+        "linear": D.ContinuousTimeGaussianDiffusion(Stub(), noise_schedule="linear"),
+        "cosine_shifted": D.ContinuousTimeGaussianDiffusion(Stub(), noise_schedule="cosine_shifted", image_d=64.0, noise_d_low=32.0),
+        "cosine_interpolated": D.ContinuousTimeGaussianDiffusion(Stub(), noise_schedule="cosine_interpolated", image_d=64.0,
+                                                                 noise_d_low=32.0, noise_d_high=256.0),
+    }
+    for name, d in cases.items():
+        cond, coef, _ = d._coefficients(t[:-1], t[1:], "ddpm", 0.0)  # row by row on 1-element tensors, like the reference
+        assert torch.equal(cond, g[f"lam_{name}"][:-1]), name
+        lam_s = g[f"lam_{name}"][1:]
+        assert torch.equal(coef[:, 2], torch.cat([lam_s[i:i + 1].sigmoid().sqrt() for i in range(len(lam_s))])), name
+    with pytest.raises(AssertionError):
+        D.ContinuousTimeGaussianDiffusion(Stub(), noise_schedule="cosine_shifted")  # needs image_d / noise_d_low
+    for name in ("cosine", "sigmoid"):
+        for T in (50, 1000):
+            beta, ab, abp, snr = D.discrete_tables(T, name)
+            assert torch.equal(beta, g[f"beta_{name}_{T}"]) and torch.equal(ab, g[f"alpha_bar_{name}_{T}"]), (name, T)
+            assert abp[0] == 1 and torch.equal(abp[1:], ab[:-1])
+
+
+def test_coordinate_encodings_match_reference(golden):
+    """(f).4: spherical-harmonics / polar-coordinate encodings (encoding.py:80-117, efficient_unet.py:220-226) as the
+    host-precomputed constant `__cenc`, against the reference's own evaluation (golden 'variants')."""
+    from r2dm_amd import encodings as E
+    from r2dm_amd.unet import EfficientUNet
+
+    g = golden("variants")
+    for enc, ch in (("spherical_harmonics", 25), ("polar_coordinates", 2), ("fourier_features", 22), (None, 0)):
+        assert E.coord_channels(enc, GOLDEN_RES) == ch
+    net = EfficientUNet(in_channels=2, resolution=GOLDEN_RES, base_channels=64, coords_encoding="spherical_harmonics")
+    assert net.in_conv.weight.shape[1] == 27 and "coords_encoding.freqs" not in net.state_dict()
+    import r2dm_amd
+
+    for enc in ("spherical_harmonics", "polar_coordinates"):  # (the golden was taken with the checkpoint's HDL-64E ray angles)
+        ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(resolution=GOLDEN_RES, coords_encoding=enc), device="cpu", show_info=False)
+        c = E.coords_constant(enc, ddpm.model.coords)
+        assert c.shape == g[f"cenc_{enc}"].shape and (c - g[f"cenc_{enc}"]).abs().max() < 3e-7, enc
+    with pytest.raises(ValueError):
+        E.coord_channels("cubemap", GOLDEN_RES)

@@ -100,6 +100,80 @@ def torch_rocm_baseline(ck, cf, B, dev):
             "sample": f"sample(batch={B}, {n} {cf['mode'].upper()} steps after 1 warm-up step), scaled to the {cf['sampler_steps']}-step sampler"}
 
 
+class BoardSampler:
+    """Shader clock and board power of the device the timed region runs on, sampled from the amdgpu hwmon files by a
+    thread (20 ms period).  The split-operand convolutions run into the 1400 W board power limit, so the sustained clock
+    -- not the 2.4 GHz the nominal MFMA peak is quoted at -- sets what the matrix pipe can deliver."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+        self.dir = None
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}" if hasattr(pr, "pci_bus_id") else None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            try:
+                slot = [ln.strip().split("=")[1] for ln in open(os.path.dirname(os.path.dirname(d)) + "/uevent") if ln.startswith("PCI_SLOT_NAME=")]
+            except OSError:
+                slot = []
+            if want and slot and slot[0].startswith(want) and os.path.exists(d + "/freq1_input"):
+                self.dir = d
+        self.samples, self._stop, self._th = [], False, threading.Thread(target=self._run, daemon=True)
+
+    def _rd(self, name):
+        try:
+            with open(f"{self.dir}/{name}") as f:
+                return int(f.read())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.samples.append((self._rd("freq1_input"), self._rd("power1_average") or self._rd("power1_input")))
+            time.sleep(0.02)
+
+    def __enter__(self):
+        if self.dir:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self.dir:
+            self._th.join()
+
+    def summary(self):
+        import statistics
+        s = self.samples[len(self.samples) // 3:]  # steady part
+        f = [a for a, _ in s if a]
+        w = [b for _, b in s if b]
+        if not f:
+            return None
+        cap = self._rd("power1_cap")
+        return {"sclk_mhz": statistics.median(f) / 1e6, "board_w": statistics.median(w) / 1e6 if w else None,
+                "power_cap_w": cap / 1e6 if cap else None, "samples": len(s), "source": self.dir}
+
+
+def hipblaslt_reference(dev):
+    """What the vendor library's bf16 GEMM (8192^3, torch.matmul -> hipBLASLt) sustains on this board, for scale: it runs
+    into the same power limit.  ~1 s."""
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(20):
+        a @ b
+    torch.cuda.synchronize()
+    n = 0
+    with BoardSampler(dev.index) as bs:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            for _ in range(20):
+                a @ b
+            n += 20
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"tflops": 2 * 8192 ** 3 * n / dt / 1e12, "board": bs.summary(), "what": "torch.matmul bf16 8192x8192x8192 (hipBLASLt), 1 s"}
+
+
 def pmc_traffic():
     """HBM bytes per conv launch from the committed PMC passes (scripts/summarize_profile.py); PMC counters cannot be
     collected from inside the timed process, so this is the figure of the last profiled run of this same command."""
@@ -119,9 +193,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x2"], default="fp32",
-                    help="fp32 (default): the parity mode BASELINE.json's metric is quoted on.  bf16x2: the optional "
-                         "reduced-precision sampling mode (SURVEY.md section 8 (f).3) -- NOT the headline number")
+    ap.add_argument("--precision", choices=["fp32", "fp32-bf16x3"], default="fp32",
+                    help="operand split of the 3x3 convolutions on the matrix pipe; both are fp32-parity modes (unet.py "
+                         "set_precision).  fp32 (default): fp16 + scaled fp16 residual in the residual blocks (3 products); "
+                         "fp32-bf16x3: three bf16 pieces everywhere (6 products; the round-1 mode)")
     ap.add_argument("--seed-base", type=int, default=0, help="first global seed (tests: reproduce one rank's shard alone)")
     ap.add_argument("--dump-samples", default=None, help="directory: every rank saves {seeds, samples} of the timed call (tests)")
     args = ap.parse_args()
@@ -149,8 +224,6 @@ def main():
     RES = cf["res"]
     ck = synthetic.synthetic_checkpoint(seed=0, resolution=RES)
     ddpm, lidar, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=B, precision=args.precision)
-    nprod = 6 if args.precision == "fp32" else 3
-    peak_split = PEAK_BF16 / nprod
     ddpm.to(dev)
     broadcast_packed_weights(ddpm.model, dev, src=0)  # rank 0 packs, everyone else adopts the blob
     seeds = shard_seeds(list(range(args.seed_base, args.seed_base + B * world)), rank, world)
@@ -168,9 +241,10 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    out = run(args.steps)
-    ev1.record()
-    barrier()
+    with BoardSampler(local) as board:
+        out = run(args.steps)
+        ev1.record()
+        barrier()
     dt = time.perf_counter() - t0
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if td.get_backend() == "nccl" else "cpu")
@@ -182,22 +256,38 @@ def main():
         os.makedirs(args.dump_samples, exist_ok=True)
         torch.save({"seeds": seeds, "samples": out.cpu()}, os.path.join(args.dump_samples, f"rank{rank}.pt"))
 
-    # Dominant kernel class (the convolution launches, ~96 % of the FLOPs and of the step time): an extra, untimed pass
-    # of a few steps with every conv launch bracketed by HIP events on the sampling stream (r2dm_profile_*).
+    # The convolution launches (~96 % of the FLOPs and of the step time), per kernel class: an extra, untimed pass of a few
+    # steps with every conv launch bracketed by HIP events on the sampling stream (r2dm_profile_*).
     conv = None
     if rank == 0:
         ddpm.model.profile_convs(True)
         psteps = min(args.steps, 4)
         run(psteps)
-        conv_ms, conv_flop, conv_n = ddpm.model.read_conv_profile()
+        classes = ddpm.model.read_conv_profile_classes()
         ddpm.model.profile_convs(False)
-        conv = {"kernel": "conv_bf16x3_* (3x3 implicit-GEMM conv on the bf16 matrix pipe, fp32 operands split exactly into 3 bf16 "
-                          "pieces, 6 products per fp32 product, fp32 accumulate; fused GN+SiLU prologue, residual / GroupNorm-"
-                          "statistics epilogue) + conv_mfma_kernel (fp32-input MFMA) for the 1x1, in_conv and out_conv launches "
-                          "(4 % of the FLOPs)",
-                "launches": conv_n, "launches_per_step": conv_n // psteps, "avg_launch_us": conv_ms * 1e3 / conv_n,
-                "algorithmic_gflop_per_launch": conv_flop / conv_n / 1e9, "tflops": conv_flop / conv_ms / 1e9,
-                "ms_per_step": conv_ms / psteps}
+        NPROD = {"conv_f16x2_kernel": 3, "conv_bf16x3_*": 6}
+        WHAT = {"conv_f16x2_kernel": "3x3 implicit-GEMM conv on the fp16 matrix pipe: fp32 operands split exactly to 22 bits (fp16 + "
+                                     "2^11-scaled fp16 residual), 3 products per fp32 product, two fp32 accumulators; fused GN+SiLU "
+                                     "prologue, residual / GroupNorm-statistics epilogue; warp-specialised, persistent",
+                "conv_bf16x3_*": "same contract on the bf16 matrix pipe: three bf16 pieces, 6 products per fp32 product",
+                "conv_mfma_kernel + conv_direct_kernel": "fp32-input MFMA (1x1, in_conv) and the direct out_conv kernel"}
+        conv = []
+        for name, ms, fl, n in classes:
+            if n == 0:
+                continue
+            e = {"kernel": name, "what": WHAT[name], "launches_per_step": n // psteps, "avg_launch_us": ms * 1e3 / n,
+                 "algorithmic_gflop_per_launch": fl / n / 1e9, "tflops": fl / ms / 1e9, "ms_per_step": ms / psteps,
+                 "share_of_conv_flops": fl / sum(c[2] for c in classes)}
+            if name in NPROD:
+                e["products_per_fp32_product"] = NPROD[name]
+                e["peak_tflops"] = PEAK_BF16 / NPROD[name] / 1e12
+                e["frac"] = e["tflops"] / e["peak_tflops"]
+                e["matrix_pipe_tflops"] = e["tflops"] * NPROD[name]  # what the MFMA units actually execute
+            else:
+                e["peak_tflops"] = PEAK_FP32 / 1e12
+                e["frac"] = e["tflops"] / e["peak_tflops"]
+            conv.append(e)
+        conv.sort(key=lambda e: -e["ms_per_step"])
 
     if rank == 0:
         S = cf["sampler_steps"]
@@ -208,29 +298,43 @@ def main():
             "metric": cf["metric"], "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16x2 (REDUCED PRECISION, optional mode)",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": cf["workload"] + f"; timed = one sample() call of --steps reverse steps, value scaled to {S} steps",
                        "baseline_config": args.config, "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
-                       "sampler": cf["mode"], "sampler_steps": S,
-                       "arithmetic": ("fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply on the bf16 matrix "
-                                      "pipe with every fp32 operand split exactly into 3 bf16 pieces (6 products, fp32-class error)"
-                                      if args.precision == "fp32" else
-                                      "fp32 tensors and accumulation; 3x3 convolution operands = 2 bf16 pieces (16 mantissa bits, 3 products)"),
+                       "sampler": cf["mode"], "sampler_steps": S, "operand_split": args.precision,
+                       "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply on the matrix pipe "
+                                     "with every fp32 operand split exactly -- fp16 + scaled fp16 residual (22 bits, 3 products, "
+                                     "residual blocks) or three bf16 pieces (24 bits, 6 products, the other 3x3 convolutions" +
+                                     ("" if args.precision == "fp32" else "; here: everywhere") + "); both measured fp32-class "
+                                     "(tests/test_hip_kernels.py::test_conv3x3_both_operand_splits)",
                        "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
-            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": peak_split / 1e12, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] * 1e12 / peak_split, "traffic": pmc_traffic() if args.config == 1 else None,
-                         "peak_definition": "dense bf16 MFMA peak 2500 TF/s / %d bf16 products per algorithmic fp32 product" % nprod,
-                         "fp32_mfma_peak": PEAK_FP32 / 1e12, "frac_of_fp32_mfma_peak": conv["tflops"] * 1e12 / PEAK_FP32,
-                         "dominant_kernel": conv,
-                         "whole_step": {"achieved": step_flops / 1e12, "frac": step_flops / peak_split,
-                                        "frac_of_fp32_mfma_peak": step_flops / PEAK_FP32,
-                                        "note": "%.2f GFLOP/image-step x batch / HIP-event time of the timed sample() call" % (cf["flop"] / 1e9)},
-                         "note": "achieved = sum of algorithmic conv FLOPs / sum of conv kernel time (HIP events on the sampling "
-                                 "stream, rank 0); traffic = HBM bytes per conv launch from the last committed rocprofv3 PMC passes "
-                                 "(profiles/conv_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE; config 1 only), null if absent; "
-                                 "algorithmic bytes per launch = 147.7 MB (config 1)"},
         }
+        dom = conv[0]
+        bsum = board.summary()
+        line["roofline"] = {
+            "bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s", "frac": dom["frac"],
+            "traffic": pmc_traffic() if args.config == 1 else None,
+            "peak_definition": "dominant kernel %s: dense 16-bit MFMA peak 2500 TF/s (2.4 GHz) / %d matrix products per algorithmic "
+                               "fp32 product" % (dom["kernel"], dom.get("products_per_fp32_product", 1)),
+            "dominant_kernel": dom, "other_conv_kernels": conv[1:],
+            "all_convs": {"tflops": sum(e["tflops"] * e["ms_per_step"] for e in conv) / sum(e["ms_per_step"] for e in conv),
+                          "ms_per_step": sum(e["ms_per_step"] for e in conv), "launches_per_step": sum(e["launches_per_step"] for e in conv)},
+            "whole_step": {"achieved": step_flops / 1e12, "frac_of_fp32_mfma_peak": step_flops / PEAK_FP32,
+                           "note": "%.2f GFLOP/image-step x batch / HIP-event time of the timed sample() call" % (cf["flop"] / 1e9)},
+            "board": bsum,
+            "note": "achieved = algorithmic conv FLOPs / kernel time of the dominant kernel class (HIP events on the sampling "
+                    "stream, rank 0, extra untimed pass); peak is the NOMINAL matrix-pipe peak at 2.4 GHz -- the board power "
+                    "limit holds the shader clock below that while these kernels run (`board`, sampled during the timed "
+                    "region; profiles/r02_power_clock.txt), as it does for hipBLASLt's bf16 GEMM (`hipblaslt_bf16_gemm`); "
+                    "traffic = HBM bytes per conv launch from the last committed rocprofv3 PMC passes "
+                    "(profiles/conv_traffic.json), config 1 only"}
+        if bsum and dom.get("products_per_fp32_product"):
+            pk = PEAK_BF16 * bsum["sclk_mhz"] / 2400.0 / dom["products_per_fp32_product"] / 1e12
+            line["roofline"]["peak_at_sustained_clock"] = pk
+            line["roofline"]["frac_at_sustained_clock"] = dom["tflops"] / pk
+        if world == 1 and not args.no_torch_baseline:
+            line["roofline"]["hipblaslt_bf16_gemm"] = hipblaslt_reference(dev)
         if world == 1 and not args.no_torch_baseline:
             tb = torch_rocm_baseline(ck, cf, B, dev)
             tb["speedup"] = value / tb["value"]

@@ -77,12 +77,23 @@ size_t r2dm_workspace_bytes(const r2dm_handle* h, int32_t batch);
 int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t batch,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* -- reduced-precision sampling (the counterpart of the reference's mixed-precision bulk mode, sample_and_save.py:70,
- *    utils/option.py:49).  The 3x3 convolutions split every fp32 operand into bf16 pieces: 3 pieces / 6 products
- *    reproduce the fp32 product to 2^-23 (default: fp32-class error, the parity mode); 2 pieces / 3 products keep 16
- *    mantissa bits per operand (~2^-16 relative error per product, still 30x tighter than fp16 autocast) at half the
- *    matrix-pipe work.  Everything else stays fp32.  h == NULL sets the mode of the single-kernel entry r2dm_conv2d_ring. */
+/* -- operand split of the 3x3 convolutions on the matrix pipe (all of them compute fp32 products to fp32 accuracy or
+ *    better; there is no reduced-precision mode -- the reference's fp16 autocast bulk mode, sample_and_save.py:70,
+ *    utils/option.py:49, has no counterpart here because the parity path is already the fast one):
+ *      pieces = 2 (default): fp16 piece + 2^11-scaled fp16 residual (exact to 22 bits), 3 products, two accumulators
+ *                 (conv_f16x2.hip) for the convolutions whose input is GroupNorm-normalised -- the residual blocks' --
+ *                 and three bf16 pieces / 6 products (conv_bf16x3.hip) for the rest (down / up-sampling convolutions,
+ *                 whose raw inputs have no a-priori bound);
+ *      pieces = 3: three bf16 pieces everywhere (fp32 operand range; the round-1 parity mode).
+ *    fp16 tops out at 65504: with pieces = 2 the GroupNorm kernels bound every normalised tensor (|gamma'| sqrt(n) +
+ *    |beta'|, Samuelson) and weight packing checks the weights; r2dm_check_range reports a violation.
+ *    h == NULL sets the mode of the single-kernel entry r2dm_conv2d_ring. */
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
+
+/* Waits for `stream` and returns non-zero (r2dm_last_error explains) if, since the last call, a forward of `h` ran an
+ * f16x2 convolution on operands that may have left the fp16 range -- its output is then not valid.  The Python wrapper
+ * calls this after every stand-alone forward and once at the end of a sampling loop. */
+int r2dm_check_range(r2dm_handle* h, void* stream);
 
 /* -- measurement aid (bench.py): when enabled, every convolution launch of a forward -- the split-bf16 3x3 kernels
  *    (conv_bf16x3_*), the fp32-MFMA kernel (conv_mfma_kernel: 1x1, in_conv) and the direct out_conv kernel, 64
@@ -90,6 +101,8 @@ int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
  *    ALGORITHMIC flops (2*B*Cout*Cin*k*k*H*W per launch) and the number of launches, then resets. */
 int r2dm_profile_enable(r2dm_handle* h, int32_t on);
 int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_t* launches);
+/* same, per kernel class: [0] conv_f16x2_kernel, [1] conv_bf16x3_*, [2] conv_mfma_kernel / conv_direct_kernel */
+int r2dm_profile_read_classes(r2dm_handle* h, double* ms3, double* flop3, int64_t* launches3);
 
 /* -- posterior update: replaces the elementwise tail of p_step
  *    (continuous_time.py:208-229, discrete_time.py:140-177).  coef is (B,8) host-computed scalars,

@@ -57,8 +57,10 @@ SIGNATURES = {
     "r2dm_workspace_bytes": (c_size_t, [_P, c_int32]),
     "r2dm_unet_forward": (c_int32, [_P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "r2dm_set_conv_pieces": (c_int32, [_P, c_int32]),
+    "r2dm_check_range": (c_int32, [_P, _P]),
     "r2dm_profile_enable": (c_int32, [_P, c_int32]),
     "r2dm_profile_read": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "r2dm_profile_read_classes": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "r2dm_posterior_step": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_float, _P]),
     "r2dm_repaint_blend": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
     "r2dm_q_step": (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P]),

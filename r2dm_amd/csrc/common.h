@@ -51,7 +51,11 @@ enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2 };
 // bf16 MFMA products per fp32 product, fp32 accumulation (conv_bf16x3.hip) -- same accuracy class, 2.7x fewer
 // matrix-pipe cycles; needs 3x3, Cin % 16 == 0, Cout % 64 == 0.
 // ALGO_DIRECT: Cout <= 4 (out_conv): HBM-bound, direct fp32 FMA convolution, weights kept OIHW (conv_direct.hip).
-enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1, ALGO_DIRECT = 2 };
+// ALGO_F16X2: fp32 operands split exactly to 22 bits into an fp16 piece and a 2^11-scaled fp16 residual, three fp16 MFMA
+// products per fp32 product, two fp32 accumulators (conv_f16x2.hip): more accurate than either of the above on the
+// matrix pipe (profiles/r02_f16x2_probe.txt) at half the products of ALGO_BF16X3, but operands must fit the fp16 range
+// -- the engine uses it for GroupNorm-normalised inputs only, behind a range flag.
+enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1, ALGO_DIRECT = 2, ALGO_F16X2 = 3 };
 
 struct ConvParams {
     Src x;               // input activation
@@ -68,8 +72,8 @@ struct ConvParams {
     int co_tile;         // 32 / 64 / 128 (must match the packing)
     int prologue;        // Prologue
     int algo = ALGO_F32; // ConvAlgo (must match the packing of `w`)
-    int pieces = 3;      // ALGO_BF16X3: bf16 pieces per fp32 operand; 3 = exact split, 6 products (fp32-class error);
-                         // 2 = reduced-precision mode, 3 products, ~2^-16 relative error
+    int pieces = 3;      // ALGO_BF16X3: bf16 pieces per fp32 operand (3 = exact split, 6 products; the 2-piece variant of
+                         // round 1 is superseded by ALGO_F16X2 and no longer dispatched)
     int sign_shift = 0;  // ALGO_BF16X3 shallow kernel: accumulator sign flips every 2^sign_shift chunks (set by the launcher)
     // optional fused GroupNorm statistics of the OUTPUT (for the GroupNorm that consumes it): per (sample, group)
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
@@ -92,6 +96,11 @@ long conv_bf16x3_packed_floats(int Cin, int Cout);
 int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);
 hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, int co_tile, hipStream_t s);
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s);
+bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
+long conv_f16x2_packed_floats(int Cin, int Cout);
+// range_flag (device int, may be nullptr): bit 0 is set if a weight does not fit the fp16 range
+hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s);
+hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s);
 
 struct GNParams {
     Src x;
@@ -104,6 +113,10 @@ struct GNParams {
     double* partial;     // scratch [B][G][splits][2]
     float2* aff;         // out [B][C]
     float* stats;        // optional out [B][G][2] (mean, rstd) for tests, may be nullptr
+    // optional device int[2]: [1] takes the running maximum (as float bits) of the bound |gamma'| sqrt(n) + |beta'| on the
+    // normalised, affine-transformed tensor (Samuelson's inequality on a standardised sample) -- ALGO_F16X2 consumers
+    // need it below 65504 ([0]: weight flag of the packer)
+    int* range_flag = nullptr;
 };
 int gn_splits(int B, int groups, long group_elems);
 int conv_stat_slots(int H, int W);  // slots per (sample, group) a convolution's fused statistics occupy

@@ -1,0 +1,602 @@
+// K2f: 3x3 ring convolution on the fp16 matrix pipe with fp32-class accuracy ("f16x2 split"), warp-specialised and
+// persistent: 4 MFMA waves + 4 staging waves per CU.
+//
+// Contract and data layout are those of conv_bf16x3.hip (reference ops.Conv2d + ops.Pad,
+// /root/reference/models/ops.py:32-49,149-173; fused GroupNorm-affine + SiLU prologue and bias / residual / scale /
+// GroupNorm-statistics epilogue of /root/reference/models/efficient_unet.py:95-110).  The arithmetic is new in round 2:
+//
+//   every fp32 operand v is split EXACTLY to 22 bits as  v = h + 2^-11 l,  h = RNE_f16(v),  l = RNE_f16(2^11 (v - h)),
+//   and a product becomes  x w = xh wh + 2^-11 (xh wl + xl wh) + O(2^-22):  THREE v_mfma_f32_32x32x16_f16 instead of the
+//   six bf16 products of the three-piece bf16 split.  The xh wh products go to one fp32 accumulator, the two cross
+//   products to a second one that is scaled by 2^-11 once, in the epilogue.
+//
+// Measured on the matrix pipe (scripts/probes/f16x2_probe.hip, profiles/r02_f16x2_probe.txt): relative rms error
+// 1.7e-7 / 2.3e-7 / 4.3e-7 at K = 576 / 1152 / 4608 against 3.6e-7 / 5.4e-7 / 1.1e-6 for the bf16 three-piece split and
+// 4.4e-7 / 6.0e-7 / 1.2e-6 for the fp32 MFMA -- the big accumulator takes one (truncating) update per tap and chunk
+// instead of six, and the mean signed error is ten times smaller, so the sign-alternation trick of conv_bf16x3.hip is
+// not needed.  Why it matters: the bf16x3 kernels run into the BOARD POWER LIMIT (1400 W, shader clock 1.83-1.89 GHz,
+// profiles/r02_power_clock.txt) -- as does hipBLASLt's bf16 GEMM -- so the only way to more images per second is fewer
+// matrix-pipe operations per product.
+//
+// Range: fp16 tops out at 65504.  The kernel runs with MODE.FP16_OVFL set (conversions saturate instead of producing
+// inf), and the engine only routes convolutions here whose input is GroupNorm-normalised (PRO_AFFINE / PRO_AFFINE_SILU);
+// gn_finalize bounds |a x + d| <= |gamma'| sqrt(n) + |beta'| per channel (Samuelson) and raises the engine's range flag
+// if that could exceed the fp16 range, in which case the forward fails loudly (engine.hip).  Weights are checked when
+// they are packed.
+//
+// Who does what (as in the round-2 timeline analysis: beside a running MFMA stream every other instruction costs issue
+// slots in whichever wave it sits, so the multiplying waves carry nothing else):
+//   waves 0..3  ("multipliers", one per SIMD): a pure MFMA stream -- per tap 12 MFMAs and the 8 ds_read_b128 of the next
+//               tap's fragments; no global memory instruction, no transform, no LDS-DMA.  The tile's epilogue.
+//   waves 4..7  ("stagers", one per SIMD): raw pixel loads two chunks ahead (inline assembly, explicit vmcnt), affine +
+//               SiLU + the f16 split of the next chunk into the other x buffer, the weight stages by LDS-DMA into an
+//               8-slot ring (seven segments of flight per stage), the addresses of the block's next tile.
+// Three block-wide barriers per chunk (one per weight stage) couple the two groups.  The block is persistent (one per
+// CU) and walks its share of the launch's (output channel tile, pixel tile) pairs; the stagers run ahead across tile
+// boundaries, so a tile's epilogue overlaps the staging of the next tile's first chunks.
+#include "common.h"
+#include "conv_bf16x3.h"
+#include "conv_epilogue.h"
+#include <stdlib.h>
+
+namespace r2dm {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+namespace f2 {
+using namespace x3;  // CO_T 64, TH 4, TW 64, XR 6, NG 2, CK 16, MR 2, NR 2
+constexpr int NPL = 2;                                      // planes: h, l
+constexpr int XS = 67;                                      // 66 columns + 1 dump column (never read)
+constexpr int XPL = NG * XR * XS;                           // 16-byte entries per plane
+constexpr int XBYTES = NPL * XPL * 16;                      // 25728
+constexpr int WSTAGE = NPL * 3 * NG * CO_T * 16;            // 12288: one kernel row of one chunk
+constexpr int RING = 8;
+constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches]
+constexpr int PATCH0 = WB0 + RING * WSTAGE;                 // 149760
+constexpr int LDS_TOTAL = PATCH0 + 4 * 1024;                // 153856
+constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
+}  // namespace f2
+
+// packed (h0, h1) and (l0, l1) of two fp32 values (low half = first value)
+__device__ __forceinline__ void split_f16x2(float v0, float v1, unsigned& ph, unsigned& pl) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);  // v_cvt_pk_f16_f32 (RNE)
+    const float r0 = (v0 - (float)h[0]) * f2::LSCALE, r1 = (v1 - (float)h[1]) * f2::LSCALE;  // exact
+    const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+    ph = __builtin_bit_cast(unsigned, h);
+    pl = __builtin_bit_cast(unsigned, l);
+}
+
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles) {
+    using namespace f2;
+    constexpr int UNITS = 3 * MR * NR, PPW = 3;   // 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager
+    constexpr int NL = PRO != PRO_NONE ? 12 : 8;  // global loads per chunk of raw pixels (+ folded affine)
+    constexpr int PER_ITER = 3 * PPW + NL;        // VMEM operations a stager issues per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave8 >= 4;  // (the multipliers are the older waves: instruction issue is arbitrated by age)
+    const int wave = wave8 & 3, t4 = tid & 255;
+
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int nTw = W / TW, nTh = H / TH;  // whole tiles only (launcher)
+    const int nCoT = p.Cout / CO_T;
+    const int nchunks = p.Cin / CK, nst = 3 * nchunks;
+    const int G = gridDim.x;
+    const int nIt = (total_tiles - (int)blockIdx.x + G - 1) / G;  // tiles of this block (grid <= total_tiles)
+    const int Q = nIt * nchunks;
+    const int c0 = p.x.c0;
+
+    // tile `it` of this block -> output channel tile, sample, tile row / column.  Integer division runs on the vector ALU:
+    // tell the compiler the results are wave-uniform, or every address derived from them becomes per-lane 64-bit arithmetic.
+    auto decode = [&](int it, int& cot, int& b, int& th, int& tw) __attribute__((always_inline)) {
+        const int L = xcd_remap((int)blockIdx.x + it * G, total_tiles);
+        cot = __builtin_amdgcn_readfirstlane(L % nCoT);
+        int t = L / nCoT;
+        tw = __builtin_amdgcn_readfirstlane(t % nTw);
+        t /= nTw;
+        th = __builtin_amdgcn_readfirstlane(t % nTh);
+        b = __builtin_amdgcn_readfirstlane(t / nTh);
+    };
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
+#ifdef F2_PROF  // timeline probe (scripts/spec_timeline.py): multiplier wave 0 and stager wave 4 of block 0 stamp s_memtime
+    int prof_i = 0;
+    auto stamp = [&](int code) __attribute__((always_inline)) {
+        if (p.prof && blockIdx.x == 0 && wave == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && prof_i < 1020) p.prof[(helper ? 1024 : 0) + prof_i] = (t << 8) | (unsigned)code;
+            ++prof_i;
+        }
+    };
+    auto stamp_real = [&](int code) __attribute__((always_inline)) {  // constant 100 MHz clock next to the shader clock
+        if (p.prof && blockIdx.x == 0 && wave == 0 && !helper) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime(), u = __builtin_amdgcn_s_memtime();
+            if (lane == 0) { p.prof[2048 + 2 * code] = t; p.prof[2048 + 2 * code + 1] = u; }
+        }
+    };
+    stamp_real(0);
+#else
+    auto stamp = [&](int) __attribute__((always_inline)) {};
+    auto stamp_real = [&](int) __attribute__((always_inline)) {};
+#endif
+
+    if (helper) {
+        // ============================================= staging waves =============================================
+        __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL: f16 conversions saturate at +-65504
+        // staging unit of this thread: one aligned quad (8 channels x 4 pixels) of one tile row (t4 < 192: interior quads;
+        // 192..215: the quad holding a halo column, the three pixels it does not need go to the dump column; 216..255
+        // repeat unit 215) -- see conv_bf16x3_stream_kernel
+        int s_row, s_g, s_col;
+        unsigned dsto[4];
+        if (t4 < 192) {
+            s_row = t4 >> 5;
+            s_g = (t4 >> 4) & 1;
+            s_col = (t4 & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dsto[e] = (unsigned)(((s_g * XR + s_row) * XS + 1 + (t4 & 15) * 4 + e) * 16);
+        } else {
+            const int u = t4 - 192 < 24 ? t4 - 192 : 23;
+            s_row = u >> 2;
+            s_g = (u >> 1) & 1;
+            const bool right = u & 1;
+            s_col = right ? TW : -4;
+            const unsigned rowb = (unsigned)((s_g * XR + s_row) * XS);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dsto[e] = (rowb + (right ? (e == 0 ? XS - 2 : XS - 1) : (e == 3 ? 0 : XS - 1))) * 16;
+        }
+
+        // ---- load cursor: the chunk whose pixels are fetched next (two to three chunks ahead of the multipliers) ----
+        int l_item = 0, l_c = 0;
+        const float* l_x0 = nullptr;
+        const float* l_x1 = nullptr;
+        const float* l_aff = nullptr;
+        long l_goff = 0;
+        bool l_ok = false;
+        auto set_load_item = [&](int it) __attribute__((always_inline)) {
+            int cot, b, th, tw;
+            decode(it, cot, b, th, tw);
+            int gc = tw * TW + s_col;
+            if (gc < 0) gc += W;
+            if (gc >= W) gc -= W;  // azimuth is periodic
+            const int gr = th * TH + s_row - 1;
+            l_ok = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
+            l_goff = (long)s_g * 8 * HW + (l_ok ? gr * W + gc : 0);
+            l_x0 = p.x.p0 + b * p.x.bs0;
+            l_x1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
+            if (PRO != PRO_NONE) l_aff = reinterpret_cast<const float*>(p.aff) + ((size_t)b * p.Cin + s_g * 8) * 2;
+        };
+        // Two register sets of raw pixels: the set filled in iteration q is transformed in iteration q+2.
+        struct RawSet {
+            f32x4 raw[8];  // 8 channels x 4 pixels
+            f32x4 ad4[4];  // (a, d) of the 8 channels
+            bool ok;       // row inside the image
+        };
+        RawSet set0, set1;
+        // The pixel loads are inline assembly, like the weight DMA: hipcc's own vmcnt bookkeeping cannot see the DMA, so a
+        // compiler-placed wait for these registers would drain the whole queue.  Every wait is explicit instead (use_set).
+        auto gload = [&](f32x4& d, const float __attribute__((address_space(1)))* q) __attribute__((always_inline)) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(q) : "memory");
+        };
+        auto load_next = [&](RawSet& r) __attribute__((always_inline)) {  // the cursor's chunk: NL loads; advances the cursor
+            const int ci0 = l_c * CK;
+            const float __attribute__((address_space(1)))* xq =
+                (const float __attribute__((address_space(1)))*)((ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW : l_x0 + (long)ci0 * HW) + l_goff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gload(r.raw[i], xq + (long)i * HW);
+            if (PRO != PRO_NONE) {
+                const float __attribute__((address_space(1)))* aq = (const float __attribute__((address_space(1)))*)(l_aff + (size_t)ci0 * 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gload(r.ad4[j], aq + 4 * j);
+            }
+            r.ok = l_ok;
+            if (l_c + 1 < nchunks)
+                ++l_c;
+            else if (l_item + 1 < nIt) {
+                l_c = 0;
+                set_load_item(++l_item);
+            }  // (past the end: the last chunk again, unused)
+        };
+        // wait until at most `newer` younger VMEM operations are in flight, then hand the set's registers to the compiler
+        auto use_set = [&](RawSet& r, auto NEWER) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NEWER)::value) : "memory");
+            asm volatile("" : "+v"(r.raw[0]), "+v"(r.raw[1]), "+v"(r.raw[2]), "+v"(r.raw[3]), "+v"(r.raw[4]), "+v"(r.raw[5]), "+v"(r.raw[6]), "+v"(r.raw[7]));
+            if (PRO != PRO_NONE) asm volatile("" : "+v"(r.ad4[0]), "+v"(r.ad4[1]), "+v"(r.ad4[2]), "+v"(r.ad4[3]));
+        };
+
+        // ---- transform: affine, SiLU (same arithmetic as conv_bf16x3_pair_kernel), f16 split, pack ----
+        unsigned xpk[NPL][4];
+        auto xf = [&](RawSet& r, float& qv0, float& qv1, float& qm0, float& qm1, int k, int sl) __attribute__((always_inline)) {
+            const int e = k >> 2, i2 = k & 3;
+            constexpr bool silu = PRO == PRO_AFFINE_SILU;
+            if (sl == 0) {
+                qv0 = r.raw[2 * i2][e];
+                qv1 = r.raw[2 * i2 + 1][e];
+                if (PRO != PRO_NONE) {
+                    qv0 = qv0 * r.ad4[i2][0] + r.ad4[i2][1];
+                    qv1 = qv1 * r.ad4[i2][2] + r.ad4[i2][3];
+                }
+#ifdef R2DM_ACCURATE_SILU  // accuracy ablation (scripts/error_budget.py): libm exp + IEEE division instead of v_exp / v_rcp
+            } else if (sl == 1) {
+                if (silu) { qv0 = qv0 / (1.0f + expf(-qv0)); qv1 = qv1 / (1.0f + expf(-qv1)); }
+            } else if (sl >= 2 && sl <= 5) {
+#else
+            } else if (sl == 1) {
+                if (silu) { qm0 = qv0 * -1.4426950408889634f; qm1 = qv1 * -1.4426950408889634f; }
+            } else if (sl == 2) {
+                if (silu) { qm0 = __builtin_amdgcn_exp2f(qm0); qm1 = __builtin_amdgcn_exp2f(qm1); }
+            } else if (sl == 3) {
+                if (silu) { qm0 = 1.0f + qm0; qm1 = 1.0f + qm1; }
+            } else if (sl == 4) {
+                if (silu) { qm0 = __builtin_amdgcn_rcpf(qm0); qm1 = __builtin_amdgcn_rcpf(qm1); }
+            } else if (sl == 5) {
+                if (silu) { qv0 *= qm0; qv1 *= qm1; }
+#endif
+            } else if (sl == 6) {
+                if (PRO == PRO_NONE) {
+                    qv0 = r.ok ? qv0 : 0.f;
+                    qv1 = r.ok ? qv1 : 0.f;
+                }
+            } else if (sl == 7) {
+#ifdef F2_NO_XF  // timing ablation (wrong results)
+                xpk[0][i2] = xpk[1][i2] = __float_as_uint(qv0);
+#else
+                split_f16x2(qv0, qv1, xpk[0][i2], xpk[1][i2]);
+#endif
+            }
+        };
+        // pixels 2*half, 2*half+1 of the thread's quad into x buffer `buf`
+        auto transform_half = [&](RawSet& r, int half, unsigned char* buf) __attribute__((always_inline)) {
+            float v0[4], v1[4], m0[4], m1[4];
+            if (PRO != PRO_NONE && half == 0) {  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r.ad4[j] = r.ok ? r.ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int e = 2 * half; e < 2 * half + 2; ++e) {
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+#ifdef F2_NO_XF
+                    if (sl != 0 && sl != 7) continue;
+#endif
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) xf(r, v0[i2], v1[i2], m0[i2], m1[i2], 4 * e + i2, sl);
+                }
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    *reinterpret_cast<u32x4*>(buf + dsto[e] + pl * (XPL * 16)) = u32x4{xpk[pl][0], xpk[pl][1], xpk[pl][2], xpk[pl][3]};
+            }
+        };
+
+        // ---- weights: LDS-DMA cursor (stage within the tile's co tile; tiles may change co tile) ----
+        // 12 pieces of 1 KiB per stage; stager w issues pieces w, w+4, w+8.  Everything but the lane offset is wave-uniform:
+        // source and LDS base go through SGPRs.
+        const unsigned lane16 = (unsigned)lane * 16;
+        int d_item = 0, d_s = 0;
+        const unsigned char* d_base = nullptr;
+        auto set_dma_item = [&](int it) __attribute__((always_inline)) {
+            int cot, b, th, tw;
+            decode(it, cot, b, th, tw);
+            d_base = wsrc + (size_t)cot * nst * WSTAGE;
+        };
+        // the cursor's stage -> ring slot `slot` (this wave's three pieces); advances the cursor (past the end: the last
+        // stage again -- harmless, keeps the vmcnt bookkeeping uniform)
+        auto dma_stage = [&](int slot) __attribute__((always_inline)) {
+            const unsigned long long sv = (unsigned long long)(d_base + (size_t)d_s * WSTAGE);  // wave-uniform: say so (SGPR operand)
+            const unsigned char* src = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
+                                                              (unsigned)__builtin_amdgcn_readfirstlane((int)sv));
+            if (d_s + 1 < nst)
+                ++d_s;
+            else if (d_item + 1 < nIt) {
+                d_s = 0;
+                set_dma_item(++d_item);
+            }
+#ifdef F2_NO_DMA  // timing ablation (wrong results)
+            if (slot >= 0) return;
+#endif
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                dma16s(src + (wave + 4 * i) * 1024, lane16, lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + (wave + 4 * i) * 1024));
+        };
+
+        // ---- prologue: ring stages 0..6 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
+        set_load_item(0);
+        set_dma_item(0);
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) dma_stage(s);
+        load_next(set0);
+        use_set(set0, ic<0>{});
+        transform_half(set0, 0, smem);
+        transform_half(set0, 1, smem);
+        load_next(set1);  // (nchunks >= 2 and the cursor saturates: harmless for a one-tile, two-chunk block)
+        load_next(set0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");  // chunk 1's pixels (and the ring stages before them)
+        __builtin_amdgcn_s_barrier();  // P
+        asm volatile("" ::: "memory");
+
+        // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
+        // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
+        // stage sigma+8, due seven barriers later.  One stage is requested per segment, right behind the barrier that frees
+        // its slot:  D0(q) = stage 3q+7, D1(q) = 3q+8, D2(q) = 3q+9.  A stage requested at the start of segment j must have
+        // landed at the end of segment j+6: two iterations' worth of younger operations may still fly.
+        // The pixels of chunk q+3 are requested in the third segment, into the register set emptied in the first two; they are
+        // transformed a whole iteration later (the other set holds chunk q+2 meanwhile).  VMEM queue of one iteration:
+        //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw(q+3) [NL] | #3
+        auto stage_iter = [&](int q, RawSet& cur) __attribute__((always_inline)) {
+            unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
+            dma_stage(3 * q + 7);                // D0
+            use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago (q = 0: landed before P)
+            transform_half(cur, 0, nbuf);        // (past the end: the last chunk again, into the buffer nobody reads)
+            stamp(10);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_ITER) : "memory");  // stage 3q+1 landed
+            stamp(11);
+            __builtin_amdgcn_s_barrier();        // #1 = B'_{3q}
+            stamp(12);
+            asm volatile("" ::: "memory");
+            dma_stage(3 * q + 8);                // D1
+            transform_half(cur, 1, nbuf);
+            stamp(13);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_ITER) : "memory");  // stage 3q+2 landed
+            stamp(14);
+            __builtin_amdgcn_s_barrier();        // #2 = B'_{3q+1}
+            stamp(15);
+            asm volatile("" ::: "memory");
+            dma_stage(3 * q + 9);                // D2
+            load_next(cur);                      // pixels of chunk q+3
+            stamp(16);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_ITER) : "memory");  // stage 3q+3 landed; this wave's x writes done
+            stamp(17);
+            __builtin_amdgcn_s_barrier();        // #3 = B'_{3q+2}: publishes x(q+1)
+            stamp(18);
+            asm volatile("" ::: "memory");
+        };
+        for (int q = 0; q < Q; q += 2) {  // (Q is even: chunks per tile are)
+            stage_iter(q, set1);
+            stage_iter(q + 1, set0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing may outlive the block
+        return;
+    }
+
+    // ============================================= multiplier waves =============================================
+    unsigned xb0[NR], xb1[NR];  // fragment addresses in x buffer 0 / 1
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int s = wave * NR + n;
+        xb0[n] = lds0 + (unsigned)(((hi * XR + (s >> 1)) * XS + (s & 1) * 32 + l31) * 16);
+        xb1[n] = xb0[n] + XBYTES;
+    }
+    const unsigned lds_w0 = lds0 + WB0 + (unsigned)((hi * CO_T + l31) * 16);
+
+    f32x16 acc[MR][NR], acl[MR][NR];  // xh wh | xh wl + xl wh (scaled by 2^11)
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = acl[m][n][r] = 0.f;
+
+    // Fragments of one tap: the l plane is used by the first two products only and is single-buffered -- the next tap's is
+    // read as soon as its last product has been issued; the h plane is needed up to the last product and is double-buffered.
+    u32x4 fa0[2][MR], fb0[2][NR], fa1[MR], fb1[NR];
+    // read of plane PL, operand WW (A m0, A m1, B n0, B n1) of tap (ky, tx); plane 0 goes to buffer NB
+    auto frag_rd = [&](const unsigned (&xb)[NR], unsigned wb, auto KY, auto TX, auto PL, auto WW, auto NB) __attribute__((always_inline)) {
+        constexpr int ky = decltype(KY)::value, tx = decltype(TX)::value, pl = decltype(PL)::value, w = decltype(WW)::value;
+        constexpr int nb = decltype(NB)::value;
+        if constexpr (w < MR) {
+            u32x4& d = pl == 0 ? fa0[nb][w] : fa1[w];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(wb), "i"(pl * (3 * NG * CO_T * 16) + tx * (NG * CO_T * 16) + w * 512));
+        } else {
+            u32x4& d = pl == 0 ? fb0[nb][w - MR] : fb1[w - MR];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(xb[w - MR]), "i"(pl * (XPL * 16) + ky * (XS * 16) + tx * 16));
+        }
+    };
+    // all fragments of a tap (0, 0) at once, in the order the taps read them: plane 0, then plane 1
+    auto frag_first = [&](unsigned wb) __attribute__((always_inline)) {
+        auto f = [&](auto PL, auto WW) __attribute__((always_inline)) { frag_rd(xb0, wb, ic<0>{}, ic<0>{}, PL, WW, ic<0>{}); };
+        f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{}); f(ic<0>{}, ic<3>{});
+        f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
+    };
+
+    // one tap = 12 units: one MFMA + at most one fragment read of the next tap.  T = tap within the chunk, PAR = parity of
+    // the chunk (x buffer PAR; tap 8 reads the next chunk's tap 0 from the other x buffer, which the stagers published at
+    // this tap's barrier -- also across a tile boundary).  Products:
+    //   xl wh -> acl | xh wl -> acl | xh wh -> acc        reads behind unit: 0-3 plane h, 4 5 wl' (A), 8 9 xl' (B)
+    // LDS returns in order, so the waits count younger reads: at the tap's start everything but xl' (2 reads) is needed,
+    // before the second product those too (4 reads of this tap are younger).  A barrier tap waits for everything first:
+    // its barrier retires a ring slot and, at ky = 2, the x buffer of the previous chunk.
+    auto tap = [&](int q, auto TT, auto PAR) __attribute__((always_inline)) {
+        constexpr int t = decltype(TT)::value, par = decltype(PAR)::value;
+        constexpr int ky = t / 3, tx = t % 3, cur = (par * 9 + t) & 1;
+        constexpr int kyn = t < 8 ? (t + 1) / 3 : 0, txn = t < 8 ? (t + 1) % 3 : 0;  // next tap
+        const int sigma = 3 * q + ky;
+        const int c = q % nchunks;
+        if (tx == 2) {
+            // B'_sigma: every multiplier has its fragments of tap (sigma, 2) in registers (ring slot sigma % 8 retires), the
+            // stagers' pieces of stage sigma+1 have landed and -- at ky == 2 -- the next chunk's x buffer is complete
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(1 + ky);
+            __builtin_amdgcn_s_barrier();
+            stamp(4 + ky);
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        }
+        const unsigned wbn = lds_w0 + (unsigned)(((t < 8 ? sigma + (kyn != ky ? 1 : 0) : sigma + 1) & (RING - 1)) * WSTAGE);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int qq = i / (MR * NR), m = (i / NR) % MR, n = i % NR;
+            if (i == 4) {
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x16& ac = qq == 2 ? acc[m][n] : acl[m][n];
+            const u32x4& ua = qq == 0 ? fa1[m] : fa0[cur][m];  // A = weights (rows = output channels), B = pixels
+            const u32x4& ub = qq == 1 ? fb1[n] : fb0[cur][n];
+            // (unit order: xh(B) wl(A) | xl(B) wh(A) | xh wh -- the A/B roles of "x" and "w" are spelled out in the reads above)
+            const f16x8 fra = __builtin_bit_cast(f16x8, ua), frb = __builtin_bit_cast(f16x8, ub);
+            if (t == 0 && c == 0 && (qq == 0 || qq == 2)) {  // first product into each accumulator of a tile: start from zero
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fra, frb, zero, 0, 0, 0);
+            } else {
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fra, frb, ac, 0, 0, 0);
+            }
+            // the next tap's fragments (at the end of a tile these are dropped -- the epilogue wants the registers -- and read
+            // again after it)
+            auto fr = [&](auto PL, auto WW) __attribute__((always_inline)) {
+                if (t < 8)
+                    frag_rd(par ? xb1 : xb0, wbn, ic<kyn>{}, ic<txn>{}, PL, WW, ic<cur ^ 1>{});
+                else
+                    frag_rd(par ? xb0 : xb1, wbn, ic<0>{}, ic<0>{}, PL, WW, ic<cur ^ 1>{});
+            };
+            if (i == 0) fr(ic<0>{}, ic<0>{});
+            if (i == 1) fr(ic<0>{}, ic<1>{});
+            if (i == 2) fr(ic<0>{}, ic<2>{});
+            if (i == 3) fr(ic<0>{}, ic<3>{});
+            if (i == 4) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 3)
+            if (i == 5) fr(ic<1>{}, ic<1>{});
+            if (i == 8) fr(ic<1>{}, ic<2>{});  // xl' (its last product was unit 7)
+            if (i == 9) fr(ic<1>{}, ic<3>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int e_item = 0, e_cot, e_b, e_th, e_tw;
+    decode(0, e_cot, e_b, e_th, e_tw);
+    auto chunk = [&](int q, auto PAR) __attribute__((always_inline)) {
+        tap(q, ic<0>{}, PAR); tap(q, ic<1>{}, PAR); tap(q, ic<2>{}, PAR);
+        tap(q, ic<3>{}, PAR); tap(q, ic<4>{}, PAR); tap(q, ic<5>{}, PAR);
+        tap(q, ic<6>{}, PAR); tap(q, ic<7>{}, PAR); tap(q, ic<8>{}, PAR);
+        if constexpr (decltype(PAR)::value == 1) {  // (tiles end on odd chunks)
+            if (q % nchunks == nchunks - 1) {  // tile finished
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
+                stamp(7);
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = __builtin_fmaf(acl[m][n][r], LINV, acc[m][n][r]);
+                // the epilogue's per-lane constants (patch addresses, butterfly selectors, ...) are recomputed here from a lane
+                // id the compiler cannot trace: hoisted out of the tile loop they would have to live in registers (or
+                // scratch) across the MFMA stream
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                f32x16 accd[1][1];
+                conv_epilogue_wide<TH, TW, MR, NR, false>(p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e,
+                                                          reinterpret_cast<float*>(smem + PATCH0) + wave * 256);
+                stamp(8);
+                if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
+                // first fragments of the next tile (its chunk 0 sits in x buffer 0, stage 3(q+1) in the ring: published at
+                // this chunk's last barrier); also after the last tile -- harmless, keeps the registers plainly defined
+                frag_first(lds_w0 + (unsigned)(((3 * (q + 1)) & (RING - 1)) * WSTAGE));
+            }
+        }
+    };
+
+    __builtin_amdgcn_s_barrier();  // P: ring stages 0..6 and chunk 0 staged
+    asm volatile("" ::: "memory");
+    frag_first(lds_w0);
+    for (int q = 0; q < Q; q += 2) {  // (Q is even: Cin % 32 == 0)
+        chunk(q, ic<0>{});
+        chunk(q + 1, ic<1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // prefetched fragments must not outlive the block
+    stamp_real(1);
+}
+
+// ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane h / l][tap in row][group][co 64][8 ch] f16 ----
+// range[0] is raised to 1 if a weight does not fit the fp16 range (|w| >= 65504); the packed value saturates.
+__global__ void pack_conv_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout, int Cin,
+                                       long total, int* __restrict__ range) {
+    using namespace f2;
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL
+    const int nchunks = Cin / CK;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int ch = r % 8;
+        r /= 8;
+        const int col = r % CO_T;
+        r /= CO_T;
+        const int g = r % NG;
+        r /= NG;
+        const int tx = r % 3;
+        r /= 3;
+        const int pl = r % NPL;
+        r /= NPL;
+        const int ky = r % 3;
+        r /= 3;
+        const int c = r % nchunks;
+        const int cot = r / nchunks;
+        const int co = cot * CO_T + col, ci = c * CK + g * 8 + ch;
+        const float v = w[((long)co * Cin + ci) * 9 + ky * 3 + tx];
+        if (!(fabsf(v) < 65504.f) && range) atomicOr(range, 1);
+        unsigned ph, pq;
+        split_f16x2(v, v, ph, pq);
+        dst[i] = (unsigned short)((pl == 0 ? ph : pq) & 0xffffu);
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+static int f2_cu_count() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return v;
+}
+
+// 3x3, whole 4 x 64 pixel tiles (the wide epilogue has no pixel predication), 64-channel output tiles, an even number of
+// 16-channel chunks, a concat seam on a chunk boundary.
+bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W) {
+    return taps == 9 && Cout % f2::CO_T == 0 && Cin % (2 * f2::CK) == 0 && H % f2::TH == 0 && W % f2::TW == 0 &&
+           H * (long)W * 16 < (1L << 31);
+}
+
+long conv_f16x2_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * f2::NPL / 2; }
+
+hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s) {
+    const long total = (long)Cout * Cin * 9 * f2::NPL;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag);
+    return hipGetLastError();
+}
+
+template <int PRO>
+static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
+    auto kern = conv_f16x2_kernel<PRO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int n_cu = f2_cu_count();
+    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2::LDS_TOTAL, s, p, (int)tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
+    if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W) || p.co_tile != 64) return hipErrorInvalidValue;
+    if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
+    if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
+#ifndef F2_PROF
+    if (p.prof != nullptr) return hipErrorInvalidValue;
+#endif
+    const long tiles = (long)(p.Cout / f2::CO_T) * (p.W / f2::TW) * (p.H / f2::TH) * p.B;
+    switch (p.prologue) {
+        case PRO_NONE: return launch_f2<PRO_NONE>(p, tiles, s);
+        case PRO_AFFINE: return launch_f2<PRO_AFFINE>(p, tiles, s);
+        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU>(p, tiles, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace r2dm

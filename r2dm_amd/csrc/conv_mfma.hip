@@ -503,6 +503,7 @@ hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int t
         return src_cin == Cin ? hipMemcpyAsync(dst, w, (size_t)Cout * Cin * taps * sizeof(float), hipMemcpyDeviceToDevice, s)
                               : hipErrorInvalidValue;
     if (algo == ALGO_BF16X3) return src_cin == Cin ? launch_pack_conv_bf16x3(w, dst, Cout, Cin, co_tile, s) : hipErrorInvalidValue;
+    if (algo == ALGO_F16X2) return hipErrorInvalidValue;  // (launch_pack_conv_f16x2: needs the range flag)
     const int nT = (Cout + co_tile - 1) / co_tile;
     const long total = (long)nT * cin_pad * taps * co_tile;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -532,6 +533,7 @@ int conv_pick_algo(int Cin, int Cout, int taps) {
 
 long conv_packed_floats(int algo, int Cin, int Cout, int taps, int co_tile, int cin_pad) {
     if (algo == ALGO_BF16X3) return conv_bf16x3_packed_floats(Cin, Cout);
+    if (algo == ALGO_F16X2) return conv_f16x2_packed_floats(Cin, Cout);
     if (algo == ALGO_DIRECT) return (long)Cout * Cin * taps;  // OIHW as is
     return (long)((Cout + co_tile - 1) / co_tile) * cin_pad * taps * co_tile;
 }
@@ -583,6 +585,7 @@ static hipError_t launch_pro(const ConvParams& p, hipStream_t s) {
 
 hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.algo == ALGO_BF16X3) return launch_conv_bf16x3(p, s);
+    if (p.algo == ALGO_F16X2) return launch_conv_f16x2(p, s);
     if (p.algo == ALGO_DIRECT) return launch_conv_direct(p, s);
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.CinPad != conv_cin_pad(p.Cin, p.taps, p.co_tile)) return hipErrorInvalidValue;

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,6 +47,10 @@ struct ConvLayer {
     int cin = 0, cout = 0, taps = 0, co_tile = 0, cin_pad = 0, algo = 0;
     int src_cin = 0, src_off = 0;  // packs input channels [src_off, src_off + cin) of a (cout, src_cin, k, k) tensor
     size_t w = 0, b = 0;  // blob offsets in floats
+    // second packing of the same weights for ALGO_F16X2 (conv_f16x2.hip): the residual blocks' 3x3 convolutions, whose
+    // input is GroupNorm-normalised; selected per launch by the handle's precision mode (r2dm_set_conv_pieces)
+    bool f2 = false;
+    size_t w_f2 = 0;
     size_t packed_elems() const { return (size_t)conv_packed_floats(algo, cin, cout, taps, co_tile, cin_pad); }
 };
 
@@ -96,7 +101,11 @@ struct r2dm_handle {
     ConvLayer in_conv_c;
     size_t cmap = 0, zero_bias = 0;
     bool cmap_ready = false;
-    int conv_pieces = 3;  // bf16 pieces per fp32 operand of the split-bf16 3x3 convolutions (r2dm_set_conv_pieces)
+    // split of the fp32 operands of the 3x3 convolutions on the matrix pipe (r2dm_set_conv_pieces): 2 = fp16 + scaled fp16
+    // residual (ALGO_F16X2) wherever a second packing exists, three bf16 pieces elsewhere; 3 = three bf16 pieces everywhere
+    int conv_pieces = 2;
+    size_t range_flag = 0;  // blob slot (two ints, ALGO_F16X2): [0] != 0: a weight outside the fp16 range; [1]: float bits of the
+                            // largest GroupNorm output bound seen since the last r2dm_check_range
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
     int ada_rows = 0;
     std::map<int, size_t> ws_cache;
@@ -105,6 +114,8 @@ struct r2dm_handle {
     std::vector<hipEvent_t> prof_ev;  // pairs
     size_t prof_used = 0;
     double prof_flop = 0.0;
+    std::vector<int> prof_cls;        // per bracketed launch: 0 = f16x2, 1 = bf16x3, 2 = fp32 MFMA / direct
+    std::vector<double> prof_lflop;   // ... and its algorithmic flops
 
     size_t take(size_t floats) {
         const size_t off = blob_floats;
@@ -132,7 +143,8 @@ struct r2dm_handle {
         slots.push_back({wkey, (int64_t)cout * src_cin * L.taps, SLOT_CONV, L.w, L});
         return L;
     }
-    ConvLayer conv(const std::string& wkey, const std::string& bkey, int cin, int cout, int ksize, long px_batch) {
+    // H, W > 0: a convolution behind a GroupNorm at that resolution -- gets the ALGO_F16X2 packing too if the shape fits
+    ConvLayer conv(const std::string& wkey, const std::string& bkey, int cin, int cout, int ksize, long px_batch, int H = 0, int W = 0) {
         ConvLayer L;
         L.cin = cin;
         L.cout = cout;
@@ -141,6 +153,11 @@ struct r2dm_handle {
         L.co_tile = L.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, px_batch) : conv_pick_co_tile(cout, L.taps, px_batch);
         L.cin_pad = L.algo != ALGO_F32 ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
         L.w = take(L.packed_elems());
+        // (at least half a wave of tiles per CU at the planned batch: below that the persistent kernel leaves CUs idle)
+        if (L.algo == ALGO_BF16X3 && H > 0 && conv_f16x2_supported(cin, cout, L.taps, H, W) && (px_batch / 256) * (cout / 64) >= 128) {
+            L.f2 = true;
+            L.w_f2 = take((size_t)conv_f16x2_packed_floats(cin, cout));
+        }
         slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
         L.b = raw(bkey, cout);
         return L;
@@ -156,6 +173,7 @@ void build_plan(r2dm_handle* h) {
                  C0 * c.channel_multiplier[3]};
     const long px1 = (long)c.height * c.width * c.max_batch;
 
+    h->range_flag = h->take(2);
     if (c.coord_channels > 0) h->cenc = h->raw("__cenc", (int64_t)c.coord_channels * c.height * c.width);
     h->freqs = h->raw("__sin_freqs", C0 / 2);
     h->w1 = h->raw("time_embedding.1.weight", (int64_t)T * C0);
@@ -214,12 +232,12 @@ void build_plan(r2dm_handle* h) {
             r.scale = h->raw(q + "scale", 1);
             r.g1 = h->raw(q + "norm1.weight", r.cin);
             r.b1 = h->raw(q + "norm1.bias", r.cin);
-            r.conv1 = h->conv(q + "conv1.weight", q + "conv1.bias", r.cin, r.cout, 3, px);
+            r.conv1 = h->conv(q + "conv1.weight", q + "conv1.bias", r.cin, r.cout, 3, px, c.height >> d.level, c.width >> d.level);
             r.ada_row = row;
             h->raw_at(q + "norm2.proj.1.weight", (int64_t)2 * r.cout * T, h->ada_w + (size_t)row * T);
             h->raw_at(q + "norm2.proj.1.bias", 2 * r.cout, h->ada_b + row);
             row += 2 * r.cout;
-            r.conv2 = h->conv(q + "conv2.weight", q + "conv2.bias", r.cout, r.cout, 3, px);
+            r.conv2 = h->conv(q + "conv2.weight", q + "conv2.bias", r.cout, r.cout, 3, px, c.height >> d.level, c.width >> d.level);
             r.has_skip = r.cin != r.cout;
             if (r.has_skip) r.skip = h->conv(q + "skip.weight", q + "skip.bias", r.cin, r.cout, 1, px);
             st.res.push_back(r);
@@ -357,12 +375,13 @@ struct Ctx {
     }
     // which convolution kernels write fused statistics: the split-bf16 kernels and the fp32-MFMA kernel with >= 64-channel
     // tiles; the 32-channel fp32 tile (Cout <= 32) and the direct kernel do not
-    static bool emits_stats(const ConvLayer& L) { return L.algo == ALGO_BF16X3 || (L.algo == ALGO_F32 && L.co_tile >= 64); }
+    static bool emits_stats(const ConvLayer& L) { return L.algo == ALGO_BF16X3 || (L.algo == ALGO_F32 && L.co_tile >= 64); }  // (and ALGO_F16X2, a second packing of a BF16X3 layer)
     float2* finalize(const Sink& k, int H, int W, const float* gamma, const float* beta, const float* ada) {
         float2* aff = (float2*)ar->alloc((size_t)B * k.C * sizeof(float2));
         if (!dry()) {
             GNParams g{Src{}, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows, k.p, aff,
                        nullptr};
+            if (h->conv_pieces == 2) g.range_flag = (int*)blob(h->range_flag);  // (only the f16x2 path has a range to guard)
             note(launch_group_norm_finalize(g, k.C, k.slots, st), "group_norm_finalize");
         }
         return aff;
@@ -378,6 +397,7 @@ struct Ctx {
         if (!dry()) {
             GNParams g{x, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows,
                        gn_partial, aff, nullptr};
+            if (h->conv_pieces == 2) g.range_flag = (int*)blob(h->range_flag);  // (only the f16x2 path has a range to guard)
             note(launch_group_norm(g, st), "group_norm");
         }
         return aff;
@@ -415,8 +435,13 @@ struct Ctx {
             p.taps = L.taps;
             p.co_tile = L.co_tile;
             p.algo = L.algo;
-            p.pieces = h->conv_pieces;
+            p.pieces = 3;
             p.prologue = pro;
+            if (L.f2 && h->conv_pieces == 2 && pro != PRO_NONE) {  // normalised input: the fp16 split (range: gn_finalize's flag)
+                p.algo = ALGO_F16X2;
+                p.w = blob(L.w_f2);
+                p.co_tile = 64;
+            }
             if (fused_stats) {
                 p.stat = sink->p;
                 p.stat_G = h->cfg.gn_num_groups;
@@ -439,7 +464,10 @@ struct Ctx {
                     h->prof_used += 2;
                     // ALGORITHMIC flops of the reference's convolution (in_conv: all 34 input channels, although the
                     // constant Fourier half is folded into a bias map here)
-                    h->prof_flop += 2.0 * B * (double)L.cout * (L.src_cin ? L.src_cin : L.cin) * L.taps * H * W;
+                    const double lf = 2.0 * B * (double)L.cout * (L.src_cin ? L.src_cin : L.cin) * L.taps * H * W;
+                    h->prof_flop += lf;
+                    h->prof_cls.push_back(p.algo == ALGO_F16X2 ? 0 : p.algo == ALGO_BF16X3 ? 1 : 2);
+                    h->prof_lflop.push_back(lf);
                     (void)hipEventRecord(e0, st);
                 }
             }
@@ -705,6 +733,31 @@ int r2dm_bind_blob(r2dm_handle* h, void* blob, size_t bytes) {
     if ((uintptr_t)blob & (kAlign - 1)) return fail(1, "blob must be %zu-byte aligned", kAlign);
     h->blob = (float*)blob;
     h->cmap_ready = false;
+    HIP_TRY(hipMemset(h->blob + h->range_flag, 0, 2 * sizeof(int)));
+    return 0;
+}
+
+int r2dm_check_range(r2dm_handle* h, void* stream) {
+    if (!h) return fail(1, "null argument");
+    if (!h->blob) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int v[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(v, h->blob + h->range_flag, sizeof(v), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float bound;
+    memcpy(&bound, &v[1], sizeof(float));
+    if (v[1] != 0) {  // per forward: reset, so that the next check reports what ran after this one
+        const int zero = 0;
+        HIP_TRY(hipMemcpyAsync(h->blob + h->range_flag + 1, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (v[0] != 0)
+        return fail(2, "a convolution weight is outside the fp16 range (|w| >= 65504) of the f16x2 convolution path; select the "
+                       "bf16x3 split with r2dm_set_conv_pieces(h, 3)");
+    if (!(bound < 65504.f))
+        return fail(2, "a GroupNorm output bound (|gamma'| sqrt(n) + |beta'| = %.3g) is outside the fp16 range (65504) of the f16x2 "
+                       "convolution path: results of this forward are not valid; select the bf16x3 split with "
+                       "r2dm_set_conv_pieces(h, 3)", (double)bound);
     return 0;
 }
 
@@ -720,6 +773,8 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
     } else {
         HIP_TRY(launch_pack_conv(src, h->blob + s.off, s.conv.cout, s.conv.cin, s.conv.taps, s.conv.co_tile,
                                  s.conv.cin_pad, st, s.conv.algo, s.conv.src_cin, s.conv.src_off));
+        if (s.conv.f2)
+            HIP_TRY(launch_pack_conv_f16x2(src, h->blob + s.conv.w_f2, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st));
     }
     h->cmap_ready = false;  // (any reload: cheap to recompute)
     return 0;
@@ -778,10 +833,10 @@ int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t
     return 0;
 }
 
-static int g_single_kernel_pieces = 3;  // r2dm_conv2d_ring (per-op tests)
+static int g_single_kernel_pieces = 2;  // r2dm_conv2d_ring (per-op tests)
 
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces) {
-    if (pieces != 2 && pieces != 3) return fail(1, "pieces must be 3 (exact split, fp32-class error) or 2 (reduced precision)");
+    if (pieces != 2 && pieces != 3) return fail(1, "pieces must be 2 (fp16 + scaled fp16 residual where the input is normalised; default) or 3 (three bf16 pieces everywhere)");
     if (h)
         h->conv_pieces = pieces;
     else
@@ -794,6 +849,27 @@ int r2dm_profile_enable(r2dm_handle* h, int32_t on) {
     h->prof_on = on != 0;
     h->prof_used = 0;
     h->prof_flop = 0.0;
+    h->prof_cls.clear();
+    h->prof_lflop.clear();
+    return 0;
+}
+
+int r2dm_profile_read_classes(r2dm_handle* h, double* ms3, double* flop3, int64_t* launches3) {
+    if (!h || !ms3 || !flop3 || !launches3) return fail(1, "null argument");
+    for (int c = 0; c < 3; ++c) { ms3[c] = 0.0; flop3[c] = 0.0; launches3[c] = 0; }
+    for (size_t i = 0; i + 1 < h->prof_used && i / 2 < h->prof_cls.size(); i += 2) {
+        HIP_TRY(hipEventSynchronize(h->prof_ev[i + 1]));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]));
+        const int c = h->prof_cls[i / 2];
+        ms3[c] += t;
+        flop3[c] += h->prof_lflop[i / 2];
+        launches3[c] += 1;
+    }
+    h->prof_used = 0;
+    h->prof_flop = 0.0;
+    h->prof_cls.clear();
+    h->prof_lflop.clear();
     return 0;
 }
 
@@ -811,6 +887,8 @@ int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_
     *launches = (int64_t)(h->prof_used / 2);
     h->prof_used = 0;
     h->prof_flop = 0.0;
+    h->prof_cls.clear();
+    h->prof_lflop.clear();
     return 0;
 }
 
@@ -820,7 +898,9 @@ int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t
     int algo = conv_pick_algo(cin, cout, taps);
     if (algo == ALGO_DIRECT) algo = ALGO_F32;  // scratch sized for the larger (fp32-MFMA) packing: either may be chosen
     const int ct = algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, taps, (long)B * H * W);
-    return (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo != ALGO_F32 ? cin : conv_cin_pad(cin, taps, ct));
+    int64_t n = (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo != ALGO_F32 ? cin : conv_cin_pad(cin, taps, ct));
+    if (algo == ALGO_BF16X3 && conv_f16x2_supported(cin, cout, taps, H, W)) n = std::max<int64_t>(n, conv_f16x2_packed_floats(cin, cout) + 64);
+    return n;
 }
 
 int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w_packed, const float* aff,
@@ -831,12 +911,20 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     hipStream_t st = (hipStream_t)stream;
     ConvParams p;
     p.taps = ksize * ksize;
-    p.pieces = g_single_kernel_pieces;
+    p.pieces = 3;
     p.algo = conv_pick_algo(cin, cout, p.taps);
     if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale)) p.algo = ALGO_F32;  // plain convolutions only
-    p.co_tile = p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    // per-op tests: with pieces = 2 every shape the f16x2 kernel covers goes there (the engine restricts it to normalised inputs)
+    if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces == 2 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
+    p.co_tile = p.algo == ALGO_F16X2 ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
     p.CinPad = p.algo != ALGO_F32 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
-    HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
+    if (p.algo == ALGO_F16X2) {  // the range flag: the last int of the scratch (r2dm_conv_packed_elems reserves it)
+        int* flag = (int*)(w_packed + conv_f16x2_packed_floats(cin, cout));
+        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, flag, st));
+    } else {
+        HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
+    }
     p.x = Src{x, nullptr, cin, 0, (long)cin * H * W, 0};
     p.w = w_packed;
     p.bias = bias;

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ ada, long ada_stride,
-                                                         float2* __restrict__ aff, float* __restrict__ stats) {
+                                                         float2* __restrict__ aff, float* __restrict__ stats,
+                                                         int* __restrict__ range_flag) {
     const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x;
     const double* p = partial + ((long)b * G + g) * splits * 2;
     double sum = 0.0, sq = 0.0;
@@ -120,6 +121,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         }
         const float a = rstd * w;
         aff[(long)b * C + c] = make_float2(a, sh - mean * a);
+        // |a (x - mean) + sh| <= |w| sqrt(n) + |sh| for every element of the group (Samuelson); SiLU only shrinks it
+        // (recorded as a running maximum -- positive floats order like their bit patterns, NaN above all -- and compared
+        // with the fp16 limit by r2dm_check_range)
+        if (range_flag) atomicMax(range_flag + 1, __float_as_int(fabsf(w) * (float)sqrt(n) + fabsf(sh)));
     }
 }
 
@@ -142,14 +147,14 @@ hipError_t launch_group_norm(const GNParams& p, hipStream_t st) {
     const int splits = gn_splits(p.B, p.groups, cpg * hw);
     gn_partial_kernel<<<dim3(splits, p.groups, p.B), kGnThreads, 0, st>>>(p.x, cpg, hw, splits, p.partial);
     gn_finalize_kernel<<<dim3(p.groups, p.B), 256, 0, st>>>(p.partial, splits, C, cpg, hw, p.eps, p.gamma, p.beta,
-                                                            p.ada, p.ada_stride, p.aff, p.stats);
+                                                            p.ada, p.ada_stride, p.aff, p.stats, p.range_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_group_norm_finalize(const GNParams& p, int C, int splits, hipStream_t st) {
     if (C % p.groups) return hipErrorInvalidValue;
     gn_finalize_kernel<<<dim3(p.groups, p.B), 256, 0, st>>>(p.partial, splits, C, C / p.groups, (long)p.H * p.W, p.eps, p.gamma,
-                                                            p.beta, p.ada, p.ada_stride, p.aff, p.stats);
+                                                            p.beta, p.ada, p.ada_stride, p.aff, p.stats, p.range_flag);
     return hipGetLastError();
 }
 

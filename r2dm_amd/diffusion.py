@@ -19,6 +19,7 @@ Training-side members (loss, timestep sampling) are out of scope (SURVEY.md sect
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from functools import partial
 from typing import List, Literal, Optional
@@ -44,6 +45,13 @@ _NCOEF = 8
 # --------------------------------------------------------------------------------------
 # log-SNR schedules (continuous_time.py:14-63).  Evaluated on the HOST in float32.
 # --------------------------------------------------------------------------------------
+def _range_guard(model):
+    """The denoiser's deferred fp16-range check (EfficientUNet.deferred_range_check) around a sampling loop: one
+    synchronising check at the end instead of one per step; a no-op for any other denoiser."""
+    guard = getattr(model, "deferred_range_check", None)
+    return guard() if callable(guard) else contextlib.nullcontext()
+
+
 def _log(t: torch.Tensor, eps: float = 1e-20) -> torch.Tensor:
     return torch.log(t.clamp(min=eps))
 
@@ -298,12 +306,13 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         cond, coef, mode_id = self._coefficients(steps[:-1], steps[1:], mode, ddim_eta)
         cond = cond[:, None].expand(num_steps, batch_size).contiguous().to(dev)
         coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
-        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-            prediction = self.model(x, cond[i])
-            noise = self.randn_like(x, rng=rng)
-            x = self._posterior(x, prediction, noise, coef[i], mode_id)
-            if return_all:
-                out.append(x)
+        with _range_guard(self.model):
+            for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+                prediction = self.model(x, cond[i])
+                noise = self.randn_like(x, rng=rng)
+                x = self._posterior(x, prediction, noise, coef[i], mode_id)
+                if return_all:
+                    out.append(x)
         return torch.stack(out) if return_all else x
 
     # -- forward process pieces used by RePaint (continuous_time.py:169-190) ----------------
@@ -353,26 +362,27 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         steps = torch.linspace(1, 0, num_steps + 1)[None].repeat_interleave(B, dim=0)
         if return_all:
             out = [x_t]
-        for i in tqdm(range(num_steps), desc="RePaint", leave=False, disable=not progress):
-            for j in range(num_resample_steps):
-                t, s = steps[:, [i]], steps[:, [i + 1]]
-                r = t + torch.linspace(0, 1, jump_length + 1)[None] * (s - t)
-                x = x_t
-                for k in range(jump_length):
-                    # q_step_from_x_0(known) and the mask blend are one kernel; the draw order (known-region noise,
-                    # then p_step's noise) is the reference's
-                    noise_k = self.randn_like(known, rng=rng)
-                    unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng)
-                    x = _lib.repaint_blend(known, noise_k, unknown_s, mask, self._alpha_sigma_rows(r[:, k + 1]).to(dev))
-                x_s = x
-                if return_all:
-                    out.append(x_s)
-                if (i == num_steps - 1) or (j == num_resample_steps - 1):
+        with _range_guard(self.model):
+            for i in tqdm(range(num_steps), desc="RePaint", leave=False, disable=not progress):
+                for j in range(num_resample_steps):
+                    t, s = steps[:, [i]], steps[:, [i + 1]]
+                    r = t + torch.linspace(0, 1, jump_length + 1)[None] * (s - t)
+                    x = x_t
+                    for k in range(jump_length):
+                        # q_step_from_x_0(known) and the mask blend are one kernel; the draw order (known-region noise,
+                        # then p_step's noise) is the reference's
+                        noise_k = self.randn_like(known, rng=rng)
+                        unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng)
+                        x = _lib.repaint_blend(known, noise_k, unknown_s, mask, self._alpha_sigma_rows(r[:, k + 1]).to(dev))
+                    x_s = x
+                    if return_all:
+                        out.append(x_s)
+                    if (i == num_steps - 1) or (j == num_resample_steps - 1):
+                        x_t = x
+                        break
+                    for k in range(jump_length, 0, -1):
+                        x = self.q_step(x, r[:, k - 1], r[:, k], rng=rng)
                     x_t = x
-                    break
-                for k in range(jump_length, 0, -1):
-                    x = self.q_step(x, r[:, k - 1], r[:, k], rng=rng)
-                x_t = x
         return torch.stack(out) if return_all else x_s
 
 
@@ -444,10 +454,11 @@ class DiscreteTimeGaussianDiffusion(GaussianDiffusion):
         coef, mode_id = self._coefficients(order, mode, 0.0)
         coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
         cond = order[:, None].expand(num_steps, batch_size).contiguous().to(dev)
-        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-            prediction = self.model(x, cond[i])
-            noise = self.randn_like(x, rng=rng) if mode_id != _M_DT_DDIM else None
-            x = self._posterior(x, prediction, noise, coef[i], mode_id)
-            if return_all:
-                out.append(x)
+        with _range_guard(self.model):
+            for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+                prediction = self.model(x, cond[i])
+                noise = self.randn_like(x, rng=rng) if mode_id != _M_DT_DDIM else None
+                x = self._posterior(x, prediction, noise, coef[i], mode_id)
+                if return_all:
+                    out.append(x)
         return torch.stack(out) if return_all else x

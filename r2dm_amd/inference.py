@@ -58,7 +58,7 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
 
     ``max_batch`` (extension) tells the HIP engine which batch size to tile its layers for -- per-seed results are
     bit-reproducible for a fixed ``max_batch`` only (different tilings sum in a different order); ``precision``
-    (extension) is ``"fp32"`` (parity mode) or ``"bf16x2"`` (reduced precision, see ``EfficientUNet.set_precision``).
+    (extension) is ``"fp32"`` (default operand split) or ``"fp32-bf16x3"`` (three bf16 pieces everywhere; see ``EfficientUNet.set_precision``).
     ``compile=True`` wraps the denoiser in ``torch.compile`` as upstream does; its forward is one ctypes call into the
     HIP library, i.e. a graph break that runs eagerly."""
     if isinstance(ckpt, (str, Path)):

@@ -14,6 +14,7 @@ parameters may have changed (load_state_dict, .to(), in-place edits are NOT trac
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 from typing import Dict, Optional
@@ -173,6 +174,7 @@ class EfficientUNet(nn.Module):
         self._engine: Optional[_Engine] = None
         self._packed_for = None
         self.precision = "fp32"
+        self._defer_range_check = False
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- generic parameter tree ----------------------------------------------------------------
@@ -254,19 +256,41 @@ class EfficientUNet(nn.Module):
             self._engine = _Engine(self.geometry, self.max_batch)
         return self._engine.blob_bytes()
 
-    # -- precision ---------------------------------------------------------------------------------
-    PRECISIONS = {"fp32": 3, "bf16x2": 2}
+    # -- operand split of the 3x3 convolutions ------------------------------------------------------------
+    PRECISIONS = {"fp32": 2, "fp32-bf16x3": 3}
 
     def set_precision(self, precision: str = "fp32"):
-        """``"fp32"`` (default): 3x3 convolutions with exactly split operands, fp32-class error -- the parity mode.
-        ``"bf16x2"``: two bf16 pieces per operand (16 mantissa bits), half the matrix-pipe work -- the counterpart of the
-        reference's mixed-precision bulk sampling (sample_and_save.py:70); everything but the 3x3 convolutions stays fp32."""
+        """Both modes compute fp32 products to fp32 accuracy or better; they differ in how the matrix pipe gets there.
+        ``"fp32"`` (default): the residual blocks' 3x3 convolutions (GroupNorm-normalised input) split every operand into an
+        fp16 piece and a scaled fp16 residual -- three MFMA products, two accumulators (conv_f16x2.hip); the remaining 3x3
+        convolutions use three bf16 pieces / six products.  ``"fp32-bf16x3"``: three bf16 pieces everywhere (full fp32
+        operand range; the round-1 parity mode, about 1.4x slower).  The fp16 path needs |operand| < 65504, which the
+        engine bounds per GroupNorm; ``check_range`` raises if the bound fails."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {precision!r}")
         self.precision = precision
         if self._engine is not None:
             _lib.check(_lib.lib().r2dm_set_conv_pieces(self._engine.h, self.PRECISIONS[precision]))
         return self
+
+    def check_range(self):
+        """Raise R2DMError if an f16x2 convolution since the last check may have seen operands outside the fp16 range
+        (synchronises the sampling stream).  Called after every stand-alone forward and at the end of a sampling loop."""
+        if self._engine is not None and self._engine.blob is not None:
+            dev = self._engine.blob.device
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().r2dm_check_range(self._engine.h, _lib.stream_ptr(dev)))
+
+    @contextlib.contextmanager
+    def deferred_range_check(self):
+        """Inside: forwards do not synchronise for the range check; it runs once on exit (sampling loops)."""
+        outer, self._defer_range_check = self._defer_range_check, True
+        try:
+            yield self
+        finally:
+            self._defer_range_check = outer
+            if not outer:
+                self.check_range()
 
     # -- measurement aid ---------------------------------------------------------------------------
     def profile_convs(self, on: bool):
@@ -280,6 +304,14 @@ class EfficientUNet(nn.Module):
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         _lib.check(_lib.lib().r2dm_profile_read(self._engine.h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
         return ms.value, fl.value, n.value
+
+    CONV_CLASSES = ("conv_f16x2_kernel", "conv_bf16x3_*", "conv_mfma_kernel + conv_direct_kernel")
+
+    def read_conv_profile_classes(self):
+        """-> [(kernel class, milliseconds, algorithmic flops, launches)] since profile_convs(True); resets."""
+        ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+        _lib.check(_lib.lib().r2dm_profile_read_classes(self._engine.h, ms, fl, n))
+        return [(self.CONV_CLASSES[i], ms[i], fl[i], n[i]) for i in range(3)]
 
     # -- the hot path ----------------------------------------------------------------------------
     @torch.compiler.disable  # one ctypes call into libr2dm_hip.so: nothing for a tracing compiler to see (runs eagerly under
@@ -296,4 +328,7 @@ class EfficientUNet(nn.Module):
         if cond.shape != (B,):
             raise ValueError(f"timesteps must have shape ({B},), got {tuple(timesteps.shape)}")
         self._ensure_packed(x.device)
-        return self._engine.forward(x, cond)
+        out = self._engine.forward(x, cond)
+        if not self._defer_range_check:
+            self.check_range()
+        return out

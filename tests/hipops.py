@@ -9,7 +9,8 @@ def _st(t):
 
 
 def set_conv_pieces(n):
-    """Mode of the single-kernel conv entry: 3 = exact split (default), 2 = reduced precision."""
+    """Operand split of the single-kernel conv entry: 2 = fp16 + scaled fp16 residual where the shape allows (default),
+    3 = three bf16 pieces."""
     _lib.check(_lib.lib().r2dm_set_conv_pieces(None, n))
 
 

@@ -234,3 +234,26 @@ def test_compile_and_autocast_wrapping_degrades_to_the_same_eager_call():
     with torch.autocast("cuda", dtype=torch.float16):
         b = wrapped.sample(batch_size=2, num_steps=3, progress=False, rng=r2dm_amd.setup_rng([0, 1], DEV))
     assert b.dtype == torch.float32 and torch.equal(a, b)
+
+
+@pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
+def test_f16x2_range_bound_fails_loudly():
+    """The fp16 operand path needs |operand| < 65504.  A GroupNorm whose gamma lets the Samuelson bound
+    |gamma| sqrt(n) + |beta| (n = 8 x 64 x 1024: sqrt(n) = 724) cross that limit must make the forward fail -- not return
+    saturated numbers -- and name the way out; the all-bf16x3 mode (fp32 operand range) runs the same weights."""
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    ck = dict(synthetic_ckpt())  # (the fixture's checkpoint is shared between tests: copy before editing)
+    ck["ema_weights"] = dict(ck["ema_weights"])
+    key = next(k for k in ck["ema_weights"] if k.endswith("d_block1.residual_blocks.0.norm1.weight"))
+    ck["ema_weights"][key] = torch.full_like(ck["ema_weights"][key], 100.0)
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    x, c = rnd(95, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
+    with pytest.raises(R2DMError, match="fp16 range"):
+        ddpm.model(x, c)
+    with pytest.raises(R2DMError, match="fp16 range"):  # ... also when the check is deferred to the end of a sampling loop
+        ddpm.sample(batch_size=2, num_steps=2, progress=False)
+    ddpm.model.set_precision("fp32-bf16x3")
+    assert torch.isfinite(ddpm.model(x, c)).all()
+    ddpm.model.check_range()  # nothing pending

@@ -29,8 +29,8 @@
 //   waves 0..3  ("multipliers", one per SIMD): a pure MFMA stream -- per tap 12 MFMAs and the 8 ds_read_b128 of the next
 //               tap's fragments; no global memory instruction, no transform, no LDS-DMA.  The tile's epilogue.
 //   waves 4..7  ("stagers", one per SIMD): raw pixel loads two chunks ahead (inline assembly, explicit vmcnt), affine +
-//               SiLU + the f16 split of the next chunk into the other x buffer, the weight stages by LDS-DMA into an
-//               8-slot ring (seven segments of flight per stage), the addresses of the block's next tile.
+//               SiLU + the f16 split of the next chunk into the other x buffer, the weight stages by LDS-DMA into a
+//               4-slot ring (three segments of flight per stage), the addresses of the block's next tile.
 // Three block-wide barriers per chunk (one per weight stage) couple the two groups.  The block is persistent (one per
 // CU) and walks its share of the launch's (output channel tile, pixel tile) pairs; the stagers run ahead across tile
 // boundaries, so a tile's epilogue overlaps the staging of the next tile's first chunks.
@@ -51,10 +51,12 @@ constexpr int XS = 67;                                      // 66 columns + 1 du
 constexpr int XPL = NG * XR * XS;                           // 16-byte entries per plane
 constexpr int XBYTES = NPL * XPL * 16;                      // 25728
 constexpr int WSTAGE = NPL * 3 * NG * CO_T * 16;            // 12288: one kernel row of one chunk
-constexpr int RING = 8;
-constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches]
-constexpr int PATCH0 = WB0 + RING * WSTAGE;                 // 149760
-constexpr int LDS_TOTAL = PATCH0 + 4 * 1024;                // 153856
+constexpr int RING = 4;
+constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches][residual]
+constexpr int PATCH0 = WB0 + RING * WSTAGE;                 // 100608
+constexpr int RESQ = 3;                                     // quarters of the residual tile prefetched into LDS (of 4)
+constexpr int RES0 = PATCH0 + 4 * 1024;                     // 104704: four waves x RESQ x 4 KiB
+constexpr int LDS_TOTAL = RES0 + 4 * RESQ * 4096;           // 153856
 constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 }  // namespace f2
 
@@ -62,7 +64,9 @@ constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 __device__ __forceinline__ void split_f16x2(float v0, float v1, unsigned& ph, unsigned& pl) {
     using f32x2 = __attribute__((ext_vector_type(2))) float;
     const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);  // v_cvt_pk_f16_f32 (RNE)
-    const float r0 = (v0 - (float)h[0]) * f2::LSCALE, r1 = (v1 - (float)h[1]) * f2::LSCALE;  // exact
+    // 2^11 (v - h), exact (a power-of-two scaling of an exact difference); written so that the fp16 -> fp32 conversion
+    // folds into v_fma_mix_f32: two instructions per value instead of three
+    const float r0 = __builtin_fmaf(-(float)h[0], f2::LSCALE, v0 * f2::LSCALE), r1 = __builtin_fmaf(-(float)h[1], f2::LSCALE, v1 * f2::LSCALE);
     const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
     ph = __builtin_bit_cast(unsigned, h);
     pl = __builtin_bit_cast(unsigned, l);
@@ -74,6 +78,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     constexpr int UNITS = 3 * MR * NR, PPW = 3;   // 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager
     constexpr int NL = PRO != PRO_NONE ? 12 : 8;  // global loads per chunk of raw pixels (+ folded affine)
     constexpr int PER_ITER = 3 * PPW + NL;        // VMEM operations a stager issues per chunk
+    // a weight stage requested at the start of segment j is due at the end of segment j + RING - 2: this many younger
+    // operations of the stager may still be in flight then (vmcnt retires in order; the queue holds loads only)
+    constexpr int STAGE_NEWER = RING == 8 ? 2 * PER_ITER : 2 * PPW + NL;
+    static_assert(RING == 4 || RING == 8, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
 
@@ -156,7 +164,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         const float* l_x0 = nullptr;
         const float* l_x1 = nullptr;
         const float* l_aff = nullptr;
-        long l_goff = 0;
+        unsigned l_voff = 0;                         // this lane's byte offset inside a channel group's planes
+        const unsigned l_avoff = (unsigned)s_g * 64;  // ... and inside a chunk's (a, d) pairs
         bool l_ok = false;
         auto set_load_item = [&](int it) __attribute__((always_inline)) {
             int cot, b, th, tw;
@@ -166,10 +175,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (gc >= W) gc -= W;  // azimuth is periodic
             const int gr = th * TH + s_row - 1;
             l_ok = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
-            l_goff = (long)s_g * 8 * HW + (l_ok ? gr * W + gc : 0);
+            l_voff = (unsigned)(s_g * 8 * HW + (l_ok ? gr * W + gc : 0)) * 4u;  // (16 HW floats < 2^31: launcher)
             l_x0 = p.x.p0 + b * p.x.bs0;
             l_x1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
-            if (PRO != PRO_NONE) l_aff = reinterpret_cast<const float*>(p.aff) + ((size_t)b * p.Cin + s_g * 8) * 2;
+            if (PRO != PRO_NONE) l_aff = reinterpret_cast<const float*>(p.aff) + (size_t)b * p.Cin * 2;
         };
         // Two register sets of raw pixels: the set filled in iteration q is transformed in iteration q+2.
         struct RawSet {
@@ -180,19 +189,24 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         RawSet set0, set1;
         // The pixel loads are inline assembly, like the weight DMA: hipcc's own vmcnt bookkeeping cannot see the DMA, so a
         // compiler-placed wait for these registers would drain the whole queue.  Every wait is explicit instead (use_set).
-        auto gload = [&](f32x4& d, const float __attribute__((address_space(1)))* q) __attribute__((always_inline)) {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(q) : "memory");
+        // (wave-uniform 64-bit base in SGPRs + one 32-bit lane offset: no per-load 64-bit vector address arithmetic)
+        auto sbase = [&](const void* q) __attribute__((always_inline)) {
+            const unsigned long long v = (unsigned long long)q;
+            return (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+        };
+        auto gload = [&](f32x4& d, const unsigned char* base, unsigned voff) __attribute__((always_inline)) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
         };
         auto load_next = [&](RawSet& r) __attribute__((always_inline)) {  // the cursor's chunk: NL loads; advances the cursor
             const int ci0 = l_c * CK;
-            const float __attribute__((address_space(1)))* xq =
-                (const float __attribute__((address_space(1)))*)((ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW : l_x0 + (long)ci0 * HW) + l_goff);
+            const unsigned char* xq = sbase(ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW : l_x0 + (long)ci0 * HW);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) gload(r.raw[i], xq + (long)i * HW);
+            for (int i = 0; i < 8; ++i) gload(r.raw[i], xq + (size_t)i * HW * 4, l_voff);
             if (PRO != PRO_NONE) {
-                const float __attribute__((address_space(1)))* aq = (const float __attribute__((address_space(1)))*)(l_aff + (size_t)ci0 * 2);
+                const unsigned char* aq = sbase(l_aff + (size_t)ci0 * 2);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gload(r.ad4[j], aq + 4 * j);
+                for (int j = 0; j < 4; ++j) gload(r.ad4[j], aq + 16 * j, l_avoff);
             }
             r.ok = l_ok;
             if (l_c + 1 < nchunks)
@@ -210,9 +224,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         };
 
         // ---- transform: affine, SiLU (same arithmetic as conv_bf16x3_pair_kernel), f16 split, pack ----
-        unsigned xpk[NPL][4];
+        unsigned xpk[2][NPL][4];
         auto xf = [&](RawSet& r, float& qv0, float& qv1, float& qm0, float& qm1, int k, int sl) __attribute__((always_inline)) {
-            const int e = k >> 2, i2 = k & 3;
+            const int e = k >> 2, i2 = k & 3, eo = e & 1;
             constexpr bool silu = PRO == PRO_AFFINE_SILU;
             if (sl == 0) {
                 qv0 = r.raw[2 * i2][e];
@@ -244,33 +258,37 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 }
             } else if (sl == 7) {
 #ifdef F2_NO_XF  // timing ablation (wrong results)
-                xpk[0][i2] = xpk[1][i2] = __float_as_uint(qv0);
+                xpk[eo][0][i2] = xpk[eo][1][i2] = __float_as_uint(qv0);
 #else
-                split_f16x2(qv0, qv1, xpk[0][i2], xpk[1][i2]);
+                split_f16x2(qv0, qv1, xpk[eo][0][i2], xpk[eo][1][i2]);
 #endif
             }
         };
         // pixels 2*half, 2*half+1 of the thread's quad into x buffer `buf`
         auto transform_half = [&](RawSet& r, int half, unsigned char* buf) __attribute__((always_inline)) {
-            float v0[4], v1[4], m0[4], m1[4];
+            float v0[2][4], v1[2][4], m0[2][4], m1[2][4];
             if (PRO != PRO_NONE && half == 0) {  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r.ad4[j] = r.ok ? r.ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            // both pixels stage by stage: eight independent dependency chains (16 values) per stage -- the stager shares its
+            // SIMD with a multiplier and cannot afford to wait for its own results (exp2 / rcp are quarter rate)
 #pragma unroll
-            for (int e = 2 * half; e < 2 * half + 2; ++e) {
-#pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
+            for (int sl = 0; sl < 8; ++sl) {
 #ifdef F2_NO_XF
-                    if (sl != 0 && sl != 7) continue;
+                if (sl != 0 && sl != 7) continue;
 #endif
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) xf(r, v0[i2], v1[i2], m0[i2], m1[i2], 4 * e + i2, sl);
-                }
+                for (int eo = 0; eo < 2; ++eo)
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) xf(r, v0[eo][i2], v1[eo][i2], m0[eo][i2], m1[eo][i2], 4 * (2 * half + eo) + i2, sl);
+            }
+#pragma unroll
+            for (int eo = 0; eo < 2; ++eo)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    *reinterpret_cast<u32x4*>(buf + dsto[e] + pl * (XPL * 16)) = u32x4{xpk[pl][0], xpk[pl][1], xpk[pl][2], xpk[pl][3]};
-            }
+                    *reinterpret_cast<u32x4*>(buf + dsto[2 * half + eo] + pl * (XPL * 16)) =
+                        u32x4{xpk[eo][pl][0], xpk[eo][pl][1], xpk[eo][pl][2], xpk[eo][pl][3]};
         };
 
         // ---- weights: LDS-DMA cursor (stage within the tile's co tile; tiles may change co tile) ----
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 dma16s(src + (wave + 4 * i) * 1024, lane16, lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + (wave + 4 * i) * 1024));
         };
 
-        // ---- prologue: ring stages 0..6 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
+        // ---- prologue: ring stages 0..RING-2 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
         set_load_item(0);
         set_dma_item(0);
 #pragma unroll
@@ -321,35 +339,35 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 
         // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
         // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
-        // stage sigma+8, due seven barriers later.  One stage is requested per segment, right behind the barrier that frees
-        // its slot:  D0(q) = stage 3q+7, D1(q) = 3q+8, D2(q) = 3q+9.  A stage requested at the start of segment j must have
-        // landed at the end of segment j+6: two iterations' worth of younger operations may still fly.
+        // stage sigma+RING, due RING-1 barriers later.  One stage is requested per segment, right behind the barrier that frees
+        // its slot:  D0(q) = stage 3q+RING-1, D1(q) = 3q+RING, D2(q) = 3q+RING+1.  A stage requested at the start of segment j
+        // must have landed at the end of segment j+RING-2 (STAGE_NEWER younger operations may still fly).
         // The pixels of chunk q+3 are requested in the third segment, into the register set emptied in the first two; they are
         // transformed a whole iteration later (the other set holds chunk q+2 meanwhile).  VMEM queue of one iteration:
         //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw(q+3) [NL] | #3
         auto stage_iter = [&](int q, RawSet& cur) __attribute__((always_inline)) {
             unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
-            dma_stage(3 * q + 7);                // D0
+            dma_stage(3 * q + RING - 1);         // D0
             use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago (q = 0: landed before P)
             transform_half(cur, 0, nbuf);        // (past the end: the last chunk again, into the buffer nobody reads)
             stamp(10);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_ITER) : "memory");  // stage 3q+1 landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+1 landed
             stamp(11);
             __builtin_amdgcn_s_barrier();        // #1 = B'_{3q}
             stamp(12);
             asm volatile("" ::: "memory");
-            dma_stage(3 * q + 8);                // D1
+            dma_stage(3 * q + RING);             // D1
             transform_half(cur, 1, nbuf);
             stamp(13);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_ITER) : "memory");  // stage 3q+2 landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+2 landed
             stamp(14);
             __builtin_amdgcn_s_barrier();        // #2 = B'_{3q+1}
             stamp(15);
             asm volatile("" ::: "memory");
-            dma_stage(3 * q + 9);                // D2
+            dma_stage(3 * q + RING + 1);         // D2
             load_next(cur);                      // pixels of chunk q+3
             stamp(16);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_ITER) : "memory");  // stage 3q+3 landed; this wave's x writes done
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+3 landed; this wave's x writes done
             stamp(17);
             __builtin_amdgcn_s_barrier();        // #3 = B'_{3q+2}: publishes x(q+1)
             stamp(18);
@@ -476,22 +494,38 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (q % nchunks == nchunks - 1) {  // tile finished
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
                 stamp(7);
+                // the epilogue's per-lane constants (patch addresses, butterfly selectors, ...) are recomputed here from a lane
+                // id the compiler cannot trace: hoisted out of the tile loop they would have to live in registers (or
+                // scratch) across the MFMA stream
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                // the two accumulators are combined first (acc + 2^-11 acl) and materialised: the second one's 64 registers then
+                // hold the residual tile, which the epilogue requests early (RES_AHEAD)
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int n = 0; n < NR; ++n)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][n][r] = __builtin_fmaf(acl[m][n][r], LINV, acc[m][n][r]);
-                // the epilogue's per-lane constants (patch addresses, butterfly selectors, ...) are recomputed here from a lane
-                // id the compiler cannot trace: hoisted out of the tile loop they would have to live in registers (or
-                // scratch) across the MFMA stream
-                int lane_e = lane;
-                asm volatile("" : "+v"(lane_e));
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 f32x16 accd[1][1];
-                conv_epilogue_wide<TH, TW, MR, NR, false>(p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e,
-                                                          reinterpret_cast<float*>(smem + PATCH0) + wave * 256);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's residual prefetch (requested a tile ago) is in LDS
+                conv_epilogue_wide<TH, TW, MR, NR, false, true, RESQ>(p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e,
+                                                                      reinterpret_cast<float*>(smem + PATCH0) + wave * 256, 1.0f,
+                                                                      reinterpret_cast<const float*>(smem + RES0) + wave * (RESQ * 1024));
                 stamp(8);
-                if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
+                // both accumulators restart from C = 0 in the next tile's first products; the compiler cannot see that the
+                // "accumulate" branch is never taken there and would keep all 128 registers alive across the epilogue: an
+                // empty definition ends the old values' lives (no instruction)
+                asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
+                asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
+                if (++e_item < nIt) {
+                    decode(e_item, e_cot, e_b, e_th, e_tw);
+                    // the next tile's residual: three quarters by LDS-DMA now, consumed a whole tile later
+                    conv_epilogue_prefetch_residual<TH, TW, MR, NR, RESQ>(p, e_b, e_th, e_tw, e_cot * CO_T, wave, lane_e,
+                                                                          lds0 + RES0 + (unsigned)(wave * (RESQ * 4096)));
+                }
                 // first fragments of the next tile (its chunk 0 sits in x buffer 0, stage 3(q+1) in the ring: published at
                 // this chunk's last barrier); also after the last tile -- harmless, keeps the registers plainly defined
                 frag_first(lds_w0 + (unsigned)(((3 * (q + 1)) & (RING - 1)) * WSTAGE));
@@ -499,7 +533,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         }
     };
 
-    __builtin_amdgcn_s_barrier();  // P: ring stages 0..6 and chunk 0 staged
+    conv_epilogue_prefetch_residual<TH, TW, MR, NR, RESQ>(p, e_b, e_th, e_tw, e_cot * CO_T, wave, lane, lds0 + RES0 + (unsigned)(wave * (RESQ * 4096)));
+    __builtin_amdgcn_s_barrier();  // P: ring stages 0..RING-2 and chunk 0 staged
     asm volatile("" ::: "memory");
     frag_first(lds_w0);
     for (int q = 0; q < Q; q += 2) {  // (Q is even: Cin % 32 == 0)

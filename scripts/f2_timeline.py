@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU-box probe: barrier / epilogue timeline of block 0 of conv_bf16x3_spec_kernel (library built with -DSPEC_PROF)."""
+"""GPU-box probe: barrier / epilogue timeline of block 0 of conv_f16x2_kernel (library built with -DF2_PROF)."""
 import os, sys, math
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

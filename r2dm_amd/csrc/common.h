@@ -79,6 +79,9 @@ struct ConvParams {
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
     double* stat = nullptr;
     int stat_G = 0, stat_goff = 0, stat_cpg = 0, stat_slots = 0;
+    // optional (wide epilogue only): range[1] takes the running maximum of |output| as float bits -- the engine asks for it
+    // when the consumer is an ALGO_F16X2 convolution with no GroupNorm in between (a down-sampling convolution)
+    int* range = nullptr;
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
 int conv_pick_algo(int Cin, int Cout, int taps);  // env R2DM_CONV_ALGO=f32 forces ALGO_F32 everywhere
@@ -129,7 +132,7 @@ hipError_t launch_gn_apply(const float* x, const float2* aff, float* y, int B, i
 hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
                             hipStream_t s);
 hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
-                          hipStream_t s);
+                          hipStream_t s, int* range = nullptr);  // range[1]: running max |output| as float bits (may be nullptr)
 
 // qkv: (B, 3C, N) channel-major [q | k | v]; out (B, C, N)
 hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s);

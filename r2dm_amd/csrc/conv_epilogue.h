@@ -208,6 +208,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
             for (int k8 = 0; k8 < 4; ++k8) r[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]];
         }
     };
+    float amax = 0.f;  // running max |output| (p.range)
     if (RES_LDS == 0) load_q(0, 0, rv[0]);
     if (RES_AHEAD) {
 #pragma unroll
@@ -245,6 +246,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
                 }
                 if (p.scale) v *= sc;
                 (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]] = v;
+                if (p.range) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (p.stat) {
                     const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
                     const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -254,6 +256,12 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
             }
         }
         if (p.stat) epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, co_u + m * 32, wave_px, lane);
+    }
+    if (p.range) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        const int bits = __float_as_int(amax);  // positive floats order like their bit patterns
+        if (lane == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
     }
 }
 

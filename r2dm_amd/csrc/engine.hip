@@ -73,6 +73,8 @@ struct Stage {
     int cin = 0, cout = 0;
     bool down = false, up = false, attn = false;
     ConvLayer dconv, uconv;
+    bool out_tracked = false;  // the stage's last convolution records max|output| in the range flag (its consumer is the next
+                               // stage's down-sampling convolution on the f16x2 path)
     std::vector<ResLayer> res;
     AttnLayer at;
 };
@@ -223,7 +225,7 @@ void build_plan(r2dm_handle* h) {
         const long px = px1 >> (2 * d.level);  // pixels*batch at the level the residual blocks run on
         const std::string p = std::string(d.name) + ".";
         if (d.down)  // the stage's first conv runs at the resolution above (efficient_unet.py:132-136)
-            st.dconv = h->conv(p + "downsample.0.weight", p + "downsample.0.bias", d.cin, d.cout, 3, px << 2);
+            st.dconv = h->conv(p + "downsample.0.weight", p + "downsample.0.bias", d.cin, d.cout, 3, px << 2, c.height >> (d.level - 1), c.width >> (d.level - 1));
         for (int i = 0; i < d.n; ++i) {
             ResLayer r;
             const std::string q = p + "residual_blocks." + std::to_string(i) + ".";
@@ -252,9 +254,17 @@ void build_plan(r2dm_handle* h) {
             st.at.proj = h->conv(q + "attn.out_proj.weight", q + "attn.out_proj.bias", d.cout, d.cout, 1, px);
         }
         if (d.up)  // upsample then conv at the finer resolution (efficient_unet.py:169-173)
-            st.uconv = h->conv(p + "upsample.1.weight", p + "upsample.1.bias", d.cout, d.cout, 3, px << 2);
+            st.uconv = h->conv(p + "upsample.1.weight", p + "upsample.1.bias", d.cout, d.cout, 3, px << 2, c.height >> (d.level - 1), c.width >> (d.level - 1));
     }
     h->out_conv = h->conv("out_conv.weight", "out_conv.bias", C0, c.out_channels, 3, px1);
+    // a down-sampling convolution on the f16x2 path needs its input's range guarded: its producer -- the previous stage's
+    // last residual block, second convolution, itself on the f16x2 path (wide epilogue) and no attention block behind it --
+    // records max|output|
+    for (int s = 0; s + 1 < 8; ++s) {
+        Stage& a = h->stages[s];
+        const Stage& b = h->stages[s + 1];
+        a.out_tracked = b.down && b.dconv.f2 && !a.attn && !a.up && !a.res.empty() && a.res.back().conv2.f2;
+    }
 }
 
 // ---- workspace arena -------------------------------------------------------------------------
@@ -405,7 +415,8 @@ struct Ctx {
 
     Tensor conv(const ConvLayer& L, const Src& x, int H, int W, int pro, const float2* aff, const Tensor* res,
                 size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0,
-                bool res_broadcast = false) {
+                bool res_broadcast = false, bool input_bounded = false,  // input_bounded: its producer tracked max|x| in the range flag
+                bool track_out = false) {                               // track_out: record max|y| there (f16x2 launches only)
         Tensor y;
         y.C = L.cout;
         y.H = H;
@@ -437,10 +448,13 @@ struct Ctx {
             p.algo = L.algo;
             p.pieces = 3;
             p.prologue = pro;
-            if (L.f2 && h->conv_pieces == 2 && pro != PRO_NONE) {  // normalised input: the fp16 split (range: gn_finalize's flag)
+            // the fp16 split where the input's range is guarded: GroupNorm-normalised (gn_finalize's bound) or tracked by its
+            // producer (fir_up2's running maximum)
+            if (L.f2 && h->conv_pieces == 2 && (pro != PRO_NONE || input_bounded)) {
                 p.algo = ALGO_F16X2;
                 p.w = blob(L.w_f2);
                 p.co_tile = 64;
+                if (track_out) p.range = (int*)blob(h->range_flag);
             }
             if (fused_stats) {
                 p.stat = sink->p;
@@ -479,7 +493,8 @@ struct Ctx {
 
     // efficient_unet.py:95-110.  `in_stats`: fused statistics of x (if its producer left them);
     // `out` / `out_goff`: where the statistics of this block's output go (the next GroupNorm's sink).
-    Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff) {
+    Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,
+                          bool track_out = false) {
         float2* a1 = norm(in_stats, x, H, W, blob(r.g1), blob(r.b1), nullptr);
         Sink s1 = make_sink(r.cout, H, W);
         Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, a1, nullptr, 0, false, nullptr, &s1, 0);
@@ -499,7 +514,7 @@ struct Ctx {
             ident.W = W;
             res = &ident;
         }
-        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, a2, res, r.scale, true, nullptr, out, out_goff);
+        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, a2, res, r.scale, true, nullptr, out, out_goff, false, false, track_out);
         ar->release(a2);
         drop(t1);
         if (r.has_skip) drop(skip);
@@ -522,13 +537,13 @@ struct Ctx {
     // efficient_unet.py:178-185.  Never frees `in`; returns a fresh tensor.  `in_stats`: fused statistics of `in` for
     // the first residual block (stages without downsampling); `out`/`out_goff`: sink of the GroupNorm that will consume
     // this stage's output (written by whichever convolution produces it last).
-    Tensor stage(const Stage& s, const Src& in, int H, int W, const Sink& in_stats, const Sink* out, int out_goff) {
+    Tensor stage(const Stage& s, const Src& in, int H, int W, const Sink& in_stats, const Sink* out, int out_goff, bool in_tracked = false) {
         Tensor cur;
         bool have = false;
         Sink carry = in_stats;  // statistics of the current tensor, owned elsewhere for the stage input
         bool carry_owned = false;
         if (s.down) {
-            Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false);
+            Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, in_tracked);
             cur = make(s.cout, H / 2, W / 2);
             if (!dry()) note(launch_fir_down2(t.p, t.bs(), cur.p, cur.bs(), B, s.cout, H, W, st), "fir_down2");
             drop(t);
@@ -550,7 +565,7 @@ struct Ctx {
                 dst = out;
                 goff = out_goff;
             }
-            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff);
+            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, last && s.out_tracked && h->conv_pieces == 2);
             if (carry_owned) drop_sink(carry);
             if (have) drop(cur);
             cur = nxt;
@@ -568,9 +583,10 @@ struct Ctx {
         if (carry_owned) drop_sink(carry);
         if (s.up) {
             Tensor u = make(s.cout, 2 * H, 2 * W);
-            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st), "fir_up2");
+            const bool track = s.uconv.f2 && h->conv_pieces == 2;  // the f16x2 convolution below needs max|u| < 65504
+            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? (int*)blob(h->range_flag) : nullptr), "fir_up2");
             drop(cur);
-            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff);
+            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track);
             drop(u);
         }
         return cur;
@@ -638,9 +654,9 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2);
     k.drop(h0);
     k.drop_sink(s_d1);
-    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2);
-    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2);
-    Tensor h4 = k.stage(S[3], src1(h3), H / 4, W / 4, Ctx::Sink{}, &s_u4, 0);
+    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2, S[0].out_tracked && h->conv_pieces == 2);
+    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2, S[1].out_tracked && h->conv_pieces == 2);
+    Tensor h4 = k.stage(S[3], src1(h3), H / 4, W / 4, Ctx::Sink{}, &s_u4, 0, S[2].out_tracked && h->conv_pieces == 2);
     Tensor u = k.stage(S[4], src1(h4), H / 8, W / 8, s_u4, &s_u3, 0);
     k.drop(h4);
     k.drop_sink(s_u4);
@@ -755,9 +771,9 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
         return fail(2, "a convolution weight is outside the fp16 range (|w| >= 65504) of the f16x2 convolution path; select the "
                        "bf16x3 split with r2dm_set_conv_pieces(h, 3)");
     if (!(bound < 65504.f))
-        return fail(2, "a GroupNorm output bound (|gamma'| sqrt(n) + |beta'| = %.3g) is outside the fp16 range (65504) of the f16x2 "
-                       "convolution path: results of this forward are not valid; select the bf16x3 split with "
-                       "r2dm_set_conv_pieces(h, 3)", (double)bound);
+        return fail(2, "an input of the f16x2 convolution path may be outside the fp16 range (65504): largest GroupNorm output bound "
+                       "(|gamma'| sqrt(n) + |beta'|) / up-sampled activation seen = %.3g; results of this forward are not valid; "
+                       "select the bf16x3 split with r2dm_set_conv_pieces(h, 3)", (double)bound);
     return 0;
 }
 

@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict_
 }
 
 // one thread -> input columns 2t, 2t+1 of row i -> a 2x4 output patch
+// range (optional): the running maximum of |output| is merged into range[1] as float bits (positive floats order like their
+// bit patterns) -- the f16x2 convolution that consumes this tensor needs it below 65504 (engine.hip, r2dm_check_range)
 __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
-                                                      long ybs, int C, int H, int W) {
+                                                      long ybs, int C, int H, int W, int* __restrict__ range) {
+    float amax = 0.f;
     const int Wh = W >> 1, Wo = W << 1;
     const long per_plane = (long)H * Wh;
     const long total = per_plane * C;
@@ -85,6 +88,18 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         float* out = y + b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 4 * t;
         *reinterpret_cast<f32x4*>(out) = e;
         *reinterpret_cast<f32x4*>(out + Wo) = o;
+        if (range) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(e[j]), fabsf(o[j])));
+        }
+    }
+    if (range) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        if ((threadIdx.x & 63) == 0) {
+            const int bits = __float_as_int(amax);
+            if (bits > __atomic_load_n(range + 1, __ATOMIC_RELAXED)) atomicMax(range + 1, bits);  // (rarely taken after the first blocks)
+        }
     }
 }
 
@@ -100,10 +115,10 @@ hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B,
     return hipGetLastError();
 }
 
-hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s) {
+hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, int* range) {
     if (W & 1) return hipErrorInvalidValue;
     const long total = (long)C * H * (W / 2);
-    fir_up2_kernel<<<dim3(grid_for(total), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
+    fir_up2_kernel<<<dim3(grid_for(total), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
     return hipGetLastError();
 }
 

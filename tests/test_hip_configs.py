@@ -257,3 +257,20 @@ def test_f16x2_range_bound_fails_loudly():
     ddpm.model.set_precision("fp32-bf16x3")
     assert torch.isfinite(ddpm.model(x, c)).all()
     ddpm.model.check_range()  # nothing pending
+
+
+@pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
+def test_f16x2_tracked_activation_range_fails_loudly():
+    """The down- and up-sampling convolutions have no GroupNorm in front: on the f16x2 path their inputs' running maximum is
+    recorded by the producing kernel (conv epilogue / fir_up2).  An input scaled so that the residual stream leaves the
+    fp16 range must make the forward fail; the bf16x3 mode computes it (finite, and equal to the reference)."""
+    from r2dm_amd._lib import R2DMError
+
+    ddpm = build(max_batch=2)
+    x, c = rnd(96, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
+    assert torch.isfinite(ddpm.model(x, c)).all()  # ordinary inputs: no complaint
+    with pytest.raises(R2DMError, match="fp16 range"):
+        ddpm.model(x * 3e6, c)
+    assert torch.isfinite(ddpm.model(x, c)).all()  # the flag is per forward
+    ddpm.model.set_precision("fp32-bf16x3")
+    assert torch.isfinite(ddpm.model(x * 3e6, c)).all()

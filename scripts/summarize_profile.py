@@ -1,38 +1,104 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/<dir> (bench kernel-trace stats + FETCH/WRITE PMC passes + bench JSON) into profiles/<tag>_*."""
-import csv, json, re, shutil, sys
+"""Turn gpurun_out/<dir> (scripts/jobs/j35.sh: bench JSON lines, rocprofv3 --kernel-trace --stats CSVs, three separate --pmc
+passes) into profiles/<tag>_*.  Usage: scripts/summarize_profile.py gpurun_out/j35 r02b"""
+import collections, csv, json, re, shutil, sys
 d, tag = sys.argv[1].rstrip('/') + '/', sys.argv[2]
 out = []
 rows = list(csv.DictReader(open(d + 'bench_kt_kernel_stats.csv')))
-out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (1x MI355X, batch 8, 2 warm-up + 16 timed + 4 profiled steps)\n")
-out.append("%-92s %7s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct"))
-for r in rows[:18]:
-    name = re.sub(r'r2dm::', '', r['Name'])[:92]
-    out.append("%-92s %7s %12.3f %10.1f %7.2f" % (name, r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
-conv = [r for r in rows if 'conv_' in r['Name'] and 'pack' not in r['Name']]
-tn = sum(float(r['TotalDurationNs']) for r in conv); nc = sum(int(r['Calls']) for r in conv)
-out.append("\nconvolution kernels (conv_bf16x3_pair / conv_bf16x3_stream / conv_mfma, all template variants): calls %d  total %.2f ms  average launch %.1f us" % (nc, tn / 1e6, tn / nc / 1e3))
-def pmc(fn, cname):
-    v = [float(r['Counter_Value']) for r in csv.DictReader(open(d + fn)) if 'conv_' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name'] and r['Counter_Name'] == cname]
-    return sum(v) / len(v), len(v)
-f, nf = pmc('bench_fetch_counter_collection.csv', 'FETCH_SIZE'); w, nw = pmc('bench_write_counter_collection.csv', 'WRITE_SIZE')
+jk = json.load(open(d + 'bench_kt.json'))
+nsteps = jk["steps"] + jk["warmup"] + min(jk["steps"], 4)  # timed + warm-up + the profiled pass
+out.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-torch-baseline   (1x MI355X, batch 8, {jk['warmup']} warm-up + {jk['steps']} timed + {min(jk['steps'], 4)} profiled steps = {nsteps} reverse steps)\n")
+out.append("%-86s %7s %9s %11s %10s %7s" % ("kernel", "calls", "per step", "total_ms", "avg_us", "pct"))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:22]:
+    name = re.sub(r'r2dm::|void |\(anonymous namespace\)::', '', r['Name'])[:86]
+    out.append("%-86s %7s %9.1f %11.3f %10.1f %7.2f" % (name, r['Calls'], int(r['Calls']) / nsteps, float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+out.append(f"\nall kernels: {tot / 1e6:.2f} ms over {nsteps} steps = {tot / 1e6 / nsteps:.3f} ms of kernel time per step; bench (same run, HIP events / wall clock): {jk['ms_per_step']:.3f} ms per step"
+           " -> the stream is busy back to back (no launch gaps to close with a hipGraph)")
+def cls(name):
+    if 'conv_f16x2_kernel' in name: return 'conv_f16x2_kernel'
+    if 'conv_bf16x3' in name and 'pack' not in name: return 'conv_bf16x3_*'
+    if ('conv_mfma' in name or 'conv_direct' in name) and 'pack' not in name: return 'conv_mfma_kernel + conv_direct_kernel'
+    return None
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    c = cls(r['Name'])
+    if c: agg[c][0] += int(r['Calls']); agg[c][1] += float(r['TotalDurationNs'])
+out.append("\nconvolution kernel classes (rocprofv3):")
+for c, (n, ns) in agg.items():
+    out.append("  %-40s calls %5d  (%.1f per step)  total %8.2f ms  average launch %6.1f us" % (c, n, n / nsteps, ns / 1e6, ns / n / 1e3))
 j = json.load(open(d + 'bench_n1.json'))
 dk = j['roofline']['dominant_kernel']
-out.append("\n# rocprofv3 --pmc FETCH_SIZE  /  --pmc WRITE_SIZE  (separate passes) -- python bench.py --no-cpu-baseline --steps 4 --warmup 1")
-out.append("convolution launches: %d / %d" % (nf, nw))
-out.append("FETCH_SIZE avg per launch: %.1f KB raw (gfx950 reports 1/2 of wide coalesced reads; this kernel mixes 16-byte pieces and scalars: between %.1f and %.1f MB)" % (f, f / 1024, 2 * f / 1024))
+out.append("in-bench HIP-event figures of the same command (bench_n1.json):")
+for e in [dk] + j['roofline']['other_conv_kernels']:
+    out.append("  %-40s launches/step %3d  average launch %6.1f us  %6.1f TF/s algorithmic  frac %.3f of %.1f TF/s" % (e['kernel'], e['launches_per_step'], e['avg_launch_us'], e['tflops'], e['frac'], e['peak_tflops']))
+
+# ---- PMC pass: matrix pipe busy
+def pmc_rows(fn):
+    return list(csv.DictReader(open(d + fn)))
+acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
+for r in pmc_rows('bench_mfma_counter_collection.csv'):
+    k = re.sub(r'r2dm::|void ', '', r['Kernel_Name']); k = k[:k.index('(')] if '(' in k else k
+    acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    if r['Counter_Name'] == 'GRBM_GUI_ACTIVE': dur[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+out.append("\n# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVES  (own pass, bench.py --steps 4 --warmup 1)")
+out.append("%-56s %6s %9s %13s %11s %11s %9s %10s" % ("kernel", "n", "avg_us", "MFMA_BUSY", "GUI_ACTIVE", "INSTS_MFMA", "pipe busy", "clock GHz"))
+for k, v in sorted(acc.items(), key=lambda kv: -sum(dur[kv[0]])):
+    if not any(s in k for s in ('conv_', 'attention')) or 'pack' in k: continue
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    us = sum(dur[k]) / len(dur[k]) / 1e3
+    busy = m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024)
+    out.append("%-56s %6d %9.1f %13.4e %11.4e %11.4e %9.3f %10.3f" % (k[:56], len(dur[k]), us, m['SQ_VALU_MFMA_BUSY_CYCLES'], m['GRBM_GUI_ACTIVE'], m['SQ_INSTS_MFMA'], busy, m['GRBM_GUI_ACTIVE'] / 8 / (us * 1e3)))
+out.append("pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / duration (counter collection serialises kernels: clocks are higher than in the free-running bench)")
+
+# ---- PMC passes: HBM traffic of the dominant kernel
+def pmc(fn, cname, pat):
+    v = [float(r['Counter_Value']) for r in pmc_rows(fn) if pat in r['Kernel_Name'] and 'pack' not in r['Kernel_Name'] and r['Counter_Name'] == cname]
+    return sum(v) / len(v), len(v)
+f, nf = pmc('bench_fetch_counter_collection.csv', 'FETCH_SIZE', 'conv_f16x2_kernel'); w, nw = pmc('bench_write_counter_collection.csv', 'WRITE_SIZE', 'conv_f16x2_kernel')
+alg_mb = 147.7 * 64 / 54  # r01: 147.7 MB averaged over all 64 conv launches; the 54 3x3 launches carry nearly all of it
+out.append("\n# rocprofv3 --pmc FETCH_SIZE  /  --pmc WRITE_SIZE  (separate passes), conv_f16x2_kernel launches only")
+out.append("launches: %d / %d" % (nf, nw))
+out.append("FETCH_SIZE avg per launch: %.1f KB raw (gfx950 reports 1/2 of wide coalesced reads, MI355X guide HBM section: between %.1f and %.1f MB)" % (f, f / 1024, 2 * f / 1024))
 out.append("WRITE_SIZE avg per launch: %.1f KB = %.1f MB" % (w, w / 1024))
-out.append("algorithmic bytes per average launch (input once + residual once + output once + weights, batch 8, 64 launches/forward): 147.7 MB")
-out.append("=> measured HBM-side traffic %.0f-%.0f MB per launch vs algorithmic 147.7 MB: no wasted re-reads (halo / weight re-reads are absorbed by L2 and the Infinity Cache);" % ((f + w) / 1024, (2 * f + w) / 1024))
-out.append("   arithmetic intensity %.1f GFLOP / 147.7 MB = %.0f FLOP/B >> ridge (2500/6 TF/s)/(8 TB/s) = 52 FLOP/B: MFMA-bound, roofline.bound = \"mfma\"." % (dk['algorithmic_gflop_per_launch'], dk['algorithmic_gflop_per_launch'] * 1e3 / 147.7))
-out.append("in-bench HIP-event average launch: %.1f us (%.1f TF/s algorithmic fp32 = %.3f of the split-bf16 ceiling 416.7 TF/s = %.3f of the fp32-MFMA peak 157.3 TF/s)  vs rocprofv3 average %.1f us." % (dk['avg_launch_us'], dk['tflops'], dk['tflops'] / 416.7, dk['tflops'] / 157.3, tn / nc / 1e3))
-out.append("bench: %.3f images/s, %.2f ms/step; cpu_baseline %.4f images/s on %d threads." % (j['value'], j['ms_per_step'], j.get('cpu_baseline', {}).get('value', float('nan')), j.get('cpu_baseline', {}).get('cores', 0)))
+out.append("algorithmic bytes per average 3x3 launch (input once + residual once + output once + weights, batch 8): ~%.0f MB" % alg_mb)
+out.append("=> HBM-side traffic %.0f-%.0f MB per launch: no wasted re-reads (halo and weight re-reads stay in L2 / Infinity Cache); intensity %.1f GFLOP / %.0f MB = %.0f FLOP/B,"
+           " far above the ridge (833 TF/s / 8 TB/s = 104 FLOP/B): roofline.bound = \"mfma\"." % ((f + w) / 1024, (2 * f + w) / 1024, dk['algorithmic_gflop_per_launch'], alg_mb, dk['algorithmic_gflop_per_launch'] * 1e3 / alg_mb))
+
+# ---- memory-bound kernels: achieved HBM GB/s from the kernel trace (config 1 shapes, batch 8: bytes per step by construction)
+MB = {  # kernel substring -> (algorithmic MB per step, what)
+    'fir_down2_kernel': (587.2, "3 launches: 128ch@64x1024, 256ch@32x512, 512ch@16x256 read + quarter-size write"),
+    'fir_up2_kernel': (293.6, "3 launches: 256ch@8x128, 128ch@16x256, 64ch@32x512 read + 4x write"),
+    'gn_partial_kernel': (117.4, "3 launches (statistics of the three FIR-down outputs): one read"),
+    'posterior_kernel': (16.8, "1 launch: x_t, prediction, noise read + x_s written, 8x2x64x1024 fp32 each"),
+}
+out.append("\n# HBM-bound kernels: algorithmic bytes per step / rocprofv3 kernel time per step")
+for pat, (mb, what) in MB.items():
+    r = [x for x in rows if pat in x['Name']]
+    if not r: continue
+    ms = sum(float(x['TotalDurationNs']) for x in r) / 1e6 / nsteps
+    out.append("  %-20s %7.1f MB/step in %6.1f us/step = %5.2f TB/s (%.0f %% of 8 TB/s)   [%s]" % (pat, mb, ms * 1e3, mb / 1e6 / (ms / 1e3), mb / 1e6 / (ms / 1e3) / 8 * 100, what))
+
+# ---- bench lines
+out.append("\n# bench.py lines of this job")
+for fn, what in (("bench_n1", "python bench.py  (default: config 1, 16 steps)"), ("bench_256", "python bench.py --steps 256 --warmup 8  (the full 256-step sampler in one timed call)"),
+                 ("bench_c2", "python bench.py --config 2  (DDIM-32, batch 32)"), ("bench_c4", "python bench.py --config 4 --steps 8  (128x2048, per-GPU batch 2)")):
+    try:
+        b = json.load(open(d + fn + '.json'))
+    except OSError:
+        continue
+    r = b['roofline']
+    out.append("%s\n    value %.3f %s  %.3f ms/step  roofline.frac %.3f (%.1f / %.1f TF/s, %s)  board %s  torch-ROCm baseline %s  cpu baseline %s" % (
+        what, b['value'], b['unit'], b['ms_per_step'], r['frac'], r['achieved'], r['peak'], r['dominant_kernel']['kernel'],
+        {k: (round(v, 1) if isinstance(v, float) else v) for k, v in (r['board'] or {}).items() if k != 'source'},
+        "%.3f images/s (x%.2f)" % (b['torch_rocm_baseline']['value'], b['torch_rocm_baseline']['speedup']) if b.get('torch_rocm_baseline') else "-",
+        "%.4f images/s on %d threads" % (b['cpu_baseline']['value'], b['cpu_baseline']['cores']) if b.get('cpu_baseline') else "-"))
+    shutil.copy(d + fn + '.json', 'profiles/%s_%s.json' % (tag, fn))
 open('profiles/%s_bench_n1_rocprof_summary.txt' % tag, 'w').write("\n".join(out) + "\n")
 shutil.copy(d + 'bench_kt_kernel_stats.csv', 'profiles/%s_bench_n1_kernel_stats.csv' % tag)
-shutil.copy(d + 'bench_n1.json', 'profiles/%s_bench_n1.json' % tag)
-json.dump({"source": "profiles/%s_bench_n1_rocprof_summary.txt" % tag, "kernel": "conv_bf16x3_pair/stream + conv_mfma (all convolution launches)", "launches": nf,
+json.dump({"source": "profiles/%s_bench_n1_rocprof_summary.txt" % tag, "kernel": "conv_f16x2_kernel (51-54 of the 64 convolution launches of a step)", "launches": nf,
            "fetch_size_kb_raw": f, "write_size_kb": w, "bytes_per_launch": (2 * f + w) * 1024,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of 16 B/lane reads as 64 B; MI355X guide, HBM section); "
                          "WRITE_SIZE as reported; separate --pmc passes"},
           open('profiles/conv_traffic.json', 'w'), indent=1)
-print("\n".join(out[-12:]))
+print("\n".join(out))

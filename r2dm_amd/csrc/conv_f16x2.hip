@@ -143,11 +143,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         int s_row, s_g, s_col;
         unsigned dsto[4];
         if (t4 < 192) {
-            s_row = t4 >> 5;
-            s_g = (t4 >> 4) & 1;
-            s_col = (t4 & 15) * 4;
+            // 16 consecutive lanes = 4 quads x 2 channel groups x 2 rows: their 16-byte LDS entries of one pixel fall into 16
+            // different bank quartets (quad stride 64 B, group stride 6432 = 32 mod 256, row stride 1072 = 48 mod 256), so the
+            // ds_write_b128 of the transform is conflict-free; with 16 lanes on 16 consecutive quads it was a 4-way conflict
+            // that took LDS cycles from the multipliers' fragment reads (round-2 timeline: +20 % on two of three segments)
+            const int qd = ((t4 >> 2) & 3) | (((t4 >> 4) & 3) << 2);
+            s_g = t4 & 1;
+            s_row = ((t4 >> 6) << 1) | ((t4 >> 1) & 1);
+            s_col = qd * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dsto[e] = (unsigned)(((s_g * XR + s_row) * XS + 1 + (t4 & 15) * 4 + e) * 16);
+            for (int e = 0; e < 4; ++e) dsto[e] = (unsigned)(((s_g * XR + s_row) * XS + 1 + qd * 4 + e) * 16);
         } else {
             const int u = t4 - 192 < 24 ? t4 - 192 : 23;
             s_row = u >> 2;
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         };
 
         // ---- weights: LDS-DMA cursor (stage within the tile's co tile; tiles may change co tile) ----
-        // 12 pieces of 1 KiB per stage; stager w issues pieces w, w+4, w+8.  Everything but the lane offset is wave-uniform:
+        // 12 pieces of 1 KiB per stage; stager w issues pieces 3w, 3w+1, 3w+2.  Everything but the lane offset is wave-uniform:
         // source and LDS base go through SGPRs.
         const unsigned lane16 = (unsigned)lane * 16;
         int d_item = 0, d_s = 0;
@@ -317,9 +322,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #ifdef F2_NO_DMA  // timing ablation (wrong results)
             if (slot >= 0) return;
 #endif
-#pragma unroll
-            for (int i = 0; i < PPW; ++i)
-                dma16s(src + (wave + 4 * i) * 1024, lane16, lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + (wave + 4 * i) * 1024));
+            // pieces 3w, 3w+1, 3w+2: one M0 set-up, the instruction offset advances the global and the LDS address together
+            {
+                const unsigned char* s3 = src + wave * (PPW * 1024);
+                const unsigned d3 = lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + wave * (PPW * 1024));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:2048"
+                             :
+                             : "v"(lane16), "s"(s3), "s"(d3)
+                             : "memory", "m0");
+            }
         };
 
         // ---- prologue: ring stages 0..RING-2 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
     };
 
+    int e_c = 0;  // chunk within the current tile
     // one tap = 12 units: one MFMA + at most one fragment read of the next tap.  T = tap within the chunk, PAR = parity of
     // the chunk (x buffer PAR; tap 8 reads the next chunk's tap 0 from the other x buffer, which the stagers published at
     // this tap's barrier -- also across a tile boundary).  Products:
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         constexpr int ky = t / 3, tx = t % 3, cur = (par * 9 + t) & 1;
         constexpr int kyn = t < 8 ? (t + 1) / 3 : 0, txn = t < 8 ? (t + 1) % 3 : 0;  // next tap
         const int sigma = 3 * q + ky;
-        const int c = q % nchunks;
+        const int c = e_c;  // chunk within the tile (a running counter: q % nchunks would be a division per chunk)
         if (tx == 2) {
             // B'_sigma: every multiplier has its fragments of tap (sigma, 2) in registers (ring slot sigma % 8 retires), the
             // stagers' pieces of stage sigma+1 have landed and -- at ky == 2 -- the next chunk's x buffer is complete
@@ -459,6 +474,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             const u32x4& ub = qq == 1 ? fb1[n] : fb0[cur][n];
             // (unit order: xh(B) wl(A) | xl(B) wh(A) | xh wh -- the A/B roles of "x" and "w" are spelled out in the reads above)
             const f16x8 fra = __builtin_bit_cast(f16x8, ua), frb = __builtin_bit_cast(f16x8, ub);
+#ifdef F2_NO_MFMA  // timing ablation (wrong results): how fast are the stagers without a multiplier on their SIMD?
+            if (i == 0) asm volatile("" :: "v"(fra), "v"(frb), "v"(ac));
+            else
+#endif
             if (t == 0 && c == 0 && (qq == 0 || qq == 2)) {  // first product into each accumulator of a tile: start from zero
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fra, frb, zero, 0, 0, 0);
@@ -490,8 +509,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         tap(q, ic<0>{}, PAR); tap(q, ic<1>{}, PAR); tap(q, ic<2>{}, PAR);
         tap(q, ic<3>{}, PAR); tap(q, ic<4>{}, PAR); tap(q, ic<5>{}, PAR);
         tap(q, ic<6>{}, PAR); tap(q, ic<7>{}, PAR); tap(q, ic<8>{}, PAR);
+        ++e_c;
         if constexpr (decltype(PAR)::value == 1) {  // (tiles end on odd chunks)
-            if (q % nchunks == nchunks - 1) {  // tile finished
+            if (e_c == nchunks) {  // tile finished
+                e_c = 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
                 stamp(7);
                 // the epilogue's per-lane constants (patch addresses, butterfly selectors, ...) are recomputed here from a lane

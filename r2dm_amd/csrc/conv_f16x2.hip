@@ -52,11 +52,13 @@ constexpr int XPL = NG * XR * XS;                           // 16-byte entries p
 constexpr int XBYTES = NPL * XPL * 16;                      // 25728
 constexpr int WSTAGE = NPL * 3 * NG * CO_T * 16;            // 12288: one kernel row of one chunk
 constexpr int RING = 4;
-constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches][residual]
+constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches][residual][(a, d) table]
 constexpr int PATCH0 = WB0 + RING * WSTAGE;                 // 100608
 constexpr int RESQ = 3;                                     // quarters of the residual tile prefetched into LDS (of 4)
 constexpr int RES0 = PATCH0 + 4 * 1024;                     // 104704: four waves x RESQ x 4 KiB
-constexpr int LDS_TOTAL = RES0 + 4 * RESQ * 4096;           // 153856
+constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;              // 153856: (a, d) of the current tile's sample, all Cin channels
+constexpr int ADTAB_BYTES = 4096;                           // Cin <= 512
+constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;             // 157952
 constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 }  // namespace f2
 
@@ -76,7 +78,7 @@ template <int PRO>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles) {
     using namespace f2;
     constexpr int UNITS = 3 * MR * NR, PPW = 3;   // 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager
-    constexpr int NL = PRO != PRO_NONE ? 12 : 8;  // global loads per chunk of raw pixels (+ folded affine)
+    constexpr int NL = 8;                         // global loads per chunk of raw pixels (the folded affine comes from an LDS table)
     constexpr int PER_ITER = 3 * PPW + NL;        // VMEM operations a stager issues per chunk
     // a weight stage requested at the start of segment j is due at the end of segment j + RING - 2: this many younger
     // operations of the stager may still be in flight then (vmcnt retires in order; the queue holds loads only)
@@ -188,7 +190,6 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         // Two register sets of raw pixels: the set filled in iteration q is transformed in iteration q+2.
         struct RawSet {
             f32x4 raw[8];  // 8 channels x 4 pixels
-            f32x4 ad4[4];  // (a, d) of the 8 channels
             bool ok;       // row inside the image
         };
         RawSet set0, set1;
@@ -208,11 +209,6 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             const unsigned char* xq = sbase(ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW : l_x0 + (long)ci0 * HW);
 #pragma unroll
             for (int i = 0; i < 8; ++i) gload(r.raw[i], xq + (size_t)i * HW * 4, l_voff);
-            if (PRO != PRO_NONE) {
-                const unsigned char* aq = sbase(l_aff + (size_t)ci0 * 2);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gload(r.ad4[j], aq + 16 * j, l_avoff);
-            }
             r.ok = l_ok;
             if (l_c + 1 < nchunks)
                 ++l_c;
@@ -225,7 +221,40 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         auto use_set = [&](RawSet& r, auto NEWER) __attribute__((always_inline)) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NEWER)::value) : "memory");
             asm volatile("" : "+v"(r.raw[0]), "+v"(r.raw[1]), "+v"(r.raw[2]), "+v"(r.raw[3]), "+v"(r.raw[4]), "+v"(r.raw[5]), "+v"(r.raw[6]), "+v"(r.raw[7]));
-            if (PRO != PRO_NONE) asm volatile("" : "+v"(r.ad4[0]), "+v"(r.ad4[1]), "+v"(r.ad4[2]), "+v"(r.ad4[3]));
+        };
+
+        // ---- the folded GroupNorm affine (a, d) of the tile's sample: Cin pairs in an LDS table, refreshed per tile ----
+        // Four more 16-byte global loads per thread and chunk were a quarter of the stagers' memory instructions (their third
+        // segment is bound by the CU's memory-instruction issue rate).  The table of tile T+1 is fetched into registers while
+        // T's second-to-last chunk is transformed and written to LDS behind the transform of T's last chunk -- the block's
+        // barrier #3 publishes it before the first chunk of T+1 is transformed.
+        f32x4 ad4[4];    // (a, d) of this thread's 8 channels of the chunk being transformed
+        f32x4 tab_v;     // table prefetch: pairs 2 t4, 2 t4 + 1 of the next tile's sample
+        int t_item = 0;  // tile whose table is in LDS
+        int x_c = 0;     // chunk (within its tile) that is transformed next
+        const f32x4* adtab = reinterpret_cast<const f32x4*>(smem + ADTAB0);
+        const bool tab_lane = PRO != PRO_NONE && t4 * 2 < p.Cin;
+        auto table_fetch = [&](int it) __attribute__((always_inline)) {  // one VMEM operation (asm: counted by hand like the others)
+            if (PRO == PRO_NONE) return;
+            int cot, b, th, tw;
+            decode(it < nIt ? it : nIt - 1, cot, b, th, tw);
+            const unsigned char* src = sbase(reinterpret_cast<const float*>(p.aff) + (size_t)b * p.Cin * 2);
+            gload(tab_v, src, tab_lane ? (unsigned)t4 * 16u : 0u);
+        };
+        auto table_store = [&](auto NEWER) __attribute__((always_inline)) {
+            if (PRO == PRO_NONE) return;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NEWER)::value) : "memory");
+            asm volatile("" : "+v"(tab_v));
+            if (tab_lane) *reinterpret_cast<f32x4*>(smem + ADTAB0 + t4 * 16) = tab_v;
+        };
+        auto table_read = [&](bool ok) __attribute__((always_inline)) {  // this thread's 8 channels of chunk x_c
+            if (PRO == PRO_NONE) return;
+            const int j0 = (x_c * CK + s_g * 8) >> 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
+                const f32x4 v = adtab[j0 + j];
+                ad4[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         };
 
         // ---- transform: affine, SiLU (same arithmetic as conv_bf16x3_pair_kernel), f16 split, pack ----
@@ -237,8 +266,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 qv0 = r.raw[2 * i2][e];
                 qv1 = r.raw[2 * i2 + 1][e];
                 if (PRO != PRO_NONE) {
-                    qv0 = qv0 * r.ad4[i2][0] + r.ad4[i2][1];
-                    qv1 = qv1 * r.ad4[i2][2] + r.ad4[i2][3];
+                    qv0 = qv0 * ad4[i2][0] + ad4[i2][1];
+                    qv1 = qv1 * ad4[i2][2] + ad4[i2][3];
                 }
 #ifdef R2DM_ACCURATE_SILU  // accuracy ablation (scripts/error_budget.py): libm exp + IEEE division instead of v_exp / v_rcp
             } else if (sl == 1) {
@@ -270,12 +299,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             }
         };
         // pixels 2*half, 2*half+1 of the thread's quad into x buffer `buf`
-        auto transform_half = [&](RawSet& r, int half, unsigned char* buf) __attribute__((always_inline)) {
+        auto transform_half = [&](RawSet& r, int half, unsigned char* buf, bool from_table = true) __attribute__((always_inline)) {
             float v0[2][4], v1[2][4], m0[2][4], m1[2][4];
-            if (PRO != PRO_NONE && half == 0) {  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r.ad4[j] = r.ok ? r.ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            if (half == 0 && from_table) table_read(r.ok);
             // both pixels stage by stage: eight independent dependency chains (16 values) per stage -- the stager shares its
             // SIMD with a multiplier and cannot afford to wait for its own results (exp2 / rcp are quarter rate)
 #pragma unroll
@@ -341,11 +367,25 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         set_dma_item(0);
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s) dma_stage(s);
+        table_fetch(0);
         load_next(set0);
+        table_store(ic<0>{});  // (all stagers write their part of the first tile's table; read below through ...
         use_set(set0, ic<0>{});
-        transform_half(set0, 0, smem);
-        transform_half(set0, 1, smem);
-        load_next(set1);  // (nchunks >= 2 and the cursor saturates: harmless for a one-tile, two-chunk block)
+        if (PRO != PRO_NONE) {  // ... this thread's own global load for chunk 0: the other waves' table writes are published by P)
+            int cot0, b0, th0, tw0;
+            decode(0, cot0, b0, th0, tw0);
+            const unsigned char* a0 = sbase(reinterpret_cast<const float*>(p.aff) + (size_t)b0 * p.Cin * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gload(ad4[j], a0 + 16 * j, (unsigned)s_g * 64u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(ad4[0]), "+v"(ad4[1]), "+v"(ad4[2]), "+v"(ad4[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ad4[j] = set0.ok ? ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        transform_half(set0, 0, smem, false);
+        transform_half(set0, 1, smem, false);
+        x_c = 1;          // (nchunks >= 4)
+        load_next(set1);  // (the cursor saturates: harmless for a one-tile, two-chunk block)
         load_next(set0);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");  // chunk 1's pixels (and the ring stages before them)
         __builtin_amdgcn_s_barrier();  // P
@@ -361,6 +401,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw(q+3) [NL] | #3
         auto stage_iter = [&](int q, RawSet& cur) __attribute__((always_inline)) {
             unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
+            const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
+            if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
             dma_stage(3 * q + RING - 1);         // D0
             use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago (q = 0: landed before P)
             transform_half(cur, 0, nbuf);        // (past the end: the last chunk again, into the buffer nobody reads)
@@ -378,6 +420,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             __builtin_amdgcn_s_barrier();        // #2 = B'_{3q+1}
             stamp(15);
             asm volatile("" ::: "memory");
+            if (last_of_tile) {                  // the next transform belongs to the next tile: its table (fetched at the start
+                table_store(ic<PER_ITER + 2 * PPW>{});  // of the previous iteration) goes to LDS
+                ++t_item;
+            }
+            x_c = last_of_tile ? 0 : x_c + 1;
             dma_stage(3 * q + RING + 1);         // D2
             load_next(cur);                      // pixels of chunk q+3
             stamp(16);
@@ -608,11 +655,11 @@ static int f2_cu_count() {
     return v;
 }
 
-// 3x3, whole 4 x 64 pixel tiles (the wide epilogue has no pixel predication), 64-channel output tiles, an even number of
-// 16-channel chunks, a concat seam on a chunk boundary.
+// 3x3, whole 4 x 64 pixel tiles (the wide epilogue has no pixel predication), 64-channel output tiles, 64 <= Cin <= 512 in
+// multiples of 64 (an even number of 16-channel chunks, at least four; the (a, d) table), a concat seam on a chunk boundary.
 bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W) {
-    return taps == 9 && Cout % f2::CO_T == 0 && Cin % (2 * f2::CK) == 0 && H % f2::TH == 0 && W % f2::TW == 0 &&
-           H * (long)W * 16 < (1L << 31);
+    return taps == 9 && Cout % f2::CO_T == 0 && Cin % (4 * f2::CK) == 0 && Cin * 8 <= f2::ADTAB_BYTES && H % f2::TH == 0 &&
+           W % f2::TW == 0 && H * (long)W * 16 < (1L << 31);
 }
 
 long conv_f16x2_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * f2::NPL / 2; }

@@ -118,7 +118,7 @@ def test_batch8_full_size_forward_vs_fp64_oracle():
         ref = O.unet_forward(sd64, cfg, x[i:i + 1].double().to(DEV), cond[i:i + 1].double().to(DEV))
         e = max_abs(y[i:i + 1].cpu(), ref.cpu())
         print(f"batch-8 forward, sample {i}: max|hip - fp64| = {e:.2e}")
-        assert e < 2e-5
+        assert e < 8e-6  # measured 2.1e-6
     assert torch.equal(y[5:6], ddpm.model(x[5:6].to(DEV), cond[5:6].to(DEV)))
 
 

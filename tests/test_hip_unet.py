@@ -83,9 +83,9 @@ def test_unet_full_size_vs_oracle():
         sd64 = {k: v.double().to(DEV) for k, v in sd.items()}
         ref64 = O.unet_forward(sd64, cfg, x.double().to(DEV), cond.double().to(DEV)).cpu()
         errs[c] = max_abs(y, ref64)
-        assert errs[c] < 2e-5, errs
+        assert errs[c] < 8e-6, errs  # measured 2.0-2.7e-6 (round 2 default path); the fp32 CPU oracle: 1.5e-6
     ref32 = O.unet_forward(sd, cfg, x, torch.full((1,), 6.0))
-    assert max_abs(ref32, ref64) < 2e-5  # the oracle's own fp32 error is of the same class
+    assert max_abs(ref32, ref64) < 6e-6  # the oracle's own fp32 error is of the same class (measured 1.5e-6)
     print("unet 64x1024 max|hip - fp64 oracle|:", errs, " fp32 oracle vs fp64:", max_abs(ref32, ref64))
 
 
@@ -319,7 +319,7 @@ def test_operand_split_modes_are_both_parity_modes():
     assert torch.equal(net(x.to(DEV), c.to(DEV)).cpu(), ya) and not torch.equal(ya, yb)
     ra, rb = rms(ya, truth), rms(yb, truth)
     print(f"U-Net 64x1024 vs fp64: f16x2 mode rms {ra:.2e} max {max_abs(ya, truth):.2e} | bf16x3 mode rms {rb:.2e} max {max_abs(yb, truth):.2e}")
-    assert ra < 6e-7 and rb < 6e-7 and max_abs(ya, truth) < 2e-5 and max_abs(yb, truth) < 2e-5
+    assert ra < 4e-7 and rb < 5.5e-7 and max_abs(ya, truth) < 8e-6 and max_abs(yb, truth) < 8e-6  # ~2x measured
     assert ra < 1.1 * rb
     with pytest.raises(ValueError):
         net.set_precision("bf16x2")  # the reduced-precision mode of round 1 is gone: the parity path is the fast one

@@ -13,6 +13,8 @@
 //                  two half-waves hold in register r -- no data movement between the two GEMMs.
 // fp32-in MFMA == fmaf chain, so this is plain fp32 attention numerically.
 #include "common.h"
+#include "conv_bf16x3.h"
+#include "f16x2.h"
 
 namespace r2dm {
 
@@ -118,19 +120,202 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
 }
 
+// ---- the same attention on the fp16 matrix pipe, operands split exactly to 22 bits (f16x2.h) ---------------------------
+// Round 2.  Per 32-key tile the fp32-MFMA kernel above issues D/2 + D/2 MFMAs of 64 cycles (4096 cycles at D = 64); here the
+// two contractions are 3 x D/16 + 3 x 2 x D/32 = 24 v_mfma_f32_32x32x16_f16 of 32 cycles (768), each with the h*h products in
+// one accumulator and the cross products in a second one.  Q (pre-multiplied by 1/sqrt(d)) is split once per wave; the K / V
+// tiles are split by the staging threads on their way into LDS (double-buffered: one barrier per tile); P is split in
+// registers -- its C-layout registers 8s..8s+7 ARE the B operand of k-step s when V's keys are stored in the matching order.
+//   LDS  Kt[buf][plane][key 32][d D (+8 pad)] f16   A operand of S^T = K^T Q : lane (key, half) reads 8 consecutive d
+//        Vs[buf][plane][d D][position 32 (+8 pad)]  A operand of O^T = V P^T : position s*16 + half*8 + j <-> key
+//                                                    s*16 + (j/4)*8 + half*4 + j%4 (the key register r = 8s + j of that half holds)
+// Range: q, k, v must fit fp16 (|v| < 65504): the engine has the producing qkv convolution record max|qkv| in the range flag
+// (r2dm_check_range); with r2dm_set_conv_pieces(h, 3) the fp32-MFMA kernel above runs instead.
+template <int D>
+__global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N,
+                                                              float scale) {
+    constexpr int KROW = D * 2 + 16, VROW = 32 * 2 + 16;          // bytes per LDS row (16 bytes of padding: conflict-free b128 reads)
+    constexpr int KPL = 32 * KROW, VPL = D * VROW;                 // bytes per plane
+    constexpr int KBUF = 2 * KPL, VBUF = 2 * VPL;                  // bytes per buffer (planes h, l)
+    constexpr int KS = D / 16, TB = D / 32;                        // k-steps of S^T, 32-row blocks of O^T
+    __shared__ __attribute__((aligned(16))) unsigned char Kt[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[2 * VBUF];
+    f16_saturate_mode();
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < N;
+
+    const float* qp = qkv + ((long)b * 3 * C + (long)h * D) * N;
+    const float* kp = qp + (long)C * N;
+    const float* vp = kp + (long)C * N;
+
+    // Q: B operand of S^T, lane (query l31, half hi) holds d = 16 s + 8 hi + 0..7 of k-step s; scaled, split once
+    u32x4 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = active ? qp[(long)(s * 16 + hi * 8 + 2 * j) * N + q0 + l31] * scale : 0.f;
+            const float c = active ? qp[(long)(s * 16 + hi * 8 + 2 * j + 1) * N + q0 + l31] * scale : 0.f;
+            unsigned uh, ul;
+            split_f16x2(a, c, uh, ul);
+            qh[s][j] = uh;
+            ql[s][j] = ul;
+        }
+
+    f32x16 o[TB], ol[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = ol[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging roles: K -- thread (key = tid & 31, d block = tid >> 5) moves 8 d of one key; V -- thread (d = tid >> 2, key octet
+    // = tid & 3) moves 8 consecutive keys of one d.  Threads beyond D / 8 d blocks (D = 32: half of them) idle.
+    const int k_key = tid & 31, k_db = tid >> 5, v_d = tid >> 2, v_kq = tid & 3;
+    const bool k_on = k_db < D / 8, v_on = v_d < D;
+    float kreg[8];
+    f32x4 vreg[2];
+    auto load_tile = [&](int kt) {
+        if (k_on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kreg[j] = kp[(long)(k_db * 8 + j) * N + kt * 32 + k_key];
+        }
+        if (v_on) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(vp + (long)v_d * N + kt * 32 + v_kq * 8);
+            vreg[0] = src[0];
+            vreg[1] = src[1];
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (k_on) {
+            unsigned ph[4], pl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_f16x2(kreg[2 * j], kreg[2 * j + 1], ph[j], pl[j]);
+            unsigned char* dst = Kt + buf * KBUF + k_key * KROW + k_db * 16;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+            *reinterpret_cast<u32x4*>(dst + KPL) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+        }
+        if (v_on) {
+            // keys v_kq*8 + t: t = 0..3 -> half 0, t = 4..7 -> half 1; position = 16 s + 8 half + 4 (v_kq & 1) + t % 4, s = v_kq >> 1
+            unsigned char* dst = Vs + buf * VBUF + v_d * VROW + ((v_kq >> 1) * 16 + (v_kq & 1) * 4) * 2;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                unsigned ph0, pl0, ph1, pl1;
+                split_f16x2(vreg[hh][0], vreg[hh][1], ph0, pl0);
+                split_f16x2(vreg[hh][2], vreg[hh][3], ph1, pl1);
+                using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+                *reinterpret_cast<u32x2*>(dst + hh * 16) = u32x2{ph0, ph1};
+                *reinterpret_cast<u32x2*>(dst + hh * 16 + VPL) = u32x2{pl0, pl1};
+            }
+        }
+    };
+
+    const int ntiles = N / 32;
+    load_tile(0);
+    store_tile(0);
+    if (ntiles > 1) load_tile(1);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) {
+            store_tile(buf ^ 1);  // (buffer of tile kt-1: everybody left it at the barrier that ended the previous iteration)
+            if (kt + 2 < ntiles) load_tile(kt + 2);
+        }
+        if (active) {
+            const unsigned char* kb = Kt + buf * KBUF + l31 * KROW + hi * 16;
+            f32x16 s, sl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = sl[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32));
+                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32 + KPL));
+                const f16x8 qhh = __builtin_bit_cast(f16x8, qh[st]), qll = __builtin_bit_cast(f16x8, ql[st]);
+                sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qhh, sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qll, sl, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qhh, s, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = fmaf(sl[r], f2::LINV, s[r]);
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __expf(s[r] - m_new);
+                psum += s[r];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[t][r] *= alpha;
+                    ol[t][r] *= alpha;
+                }
+            // P^T: registers 8 st .. 8 st + 7 are this lane's eight keys of k-step st (see the V layout above)
+            const unsigned char* vb = Vs + buf * VBUF + l31 * VROW + hi * 16;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                unsigned ph[4], pl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_f16x2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1], ph[j], pl[j]);
+                const f16x8 phh = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
+                const f16x8 pll = __builtin_bit_cast(f16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    const f16x8 vh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(vb + t * 32 * VROW + st * 32));
+                    const f16x8 vl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(vb + t * 32 * VROW + st * 32 + VPL));
+                    ol[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, phh, ol[t], 0, 0, 0);
+                    ol[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pll, ol[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, phh, o[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    float* op = out + ((long)b * C + (long)h * D) * N + q0 + l31;
+#pragma unroll
+    for (int t = 0; t < TB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            op[(long)e * N] = fmaf(ol[t][r], f2::LINV, o[t][r]) * inv;
+        }
+}
+
 bool attention_supported(int C, int heads, int N) {
     if (heads <= 0 || C % heads) return false;
     const int d = C / heads;
     return (d == 32 || d == 64) && N % 32 == 0 && N > 0;
 }
 
-hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s) {
+// f16x2: the fp16-matrix-pipe kernel (q, k, v must fit the fp16 range: the caller guards it); else the fp32-MFMA kernel
+hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, bool f16x2) {
     if (!attention_supported(C, heads, N)) return hipErrorInvalidValue;
     const int d = C / heads;
     const dim3 g((N / 32 + 3) / 4, heads, B);
     const float scale = 1.0f / sqrtf((float)d);
-    if (d == 64) attention_kernel<64><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
-    else attention_kernel<32><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+    if (f16x2) {
+        if (d == 64) attention_f16x2_kernel<64><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+        else attention_f16x2_kernel<32><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+    } else {
+        if (d == 64) attention_kernel<64><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+        else attention_kernel<32><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+    }
     return hipGetLastError();
 }
 

@@ -79,8 +79,8 @@ struct ConvParams {
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
     double* stat = nullptr;
     int stat_G = 0, stat_goff = 0, stat_cpg = 0, stat_slots = 0;
-    // optional (wide epilogue only): range[1] takes the running maximum of |output| as float bits -- the engine asks for it
-    // when the consumer is an ALGO_F16X2 convolution with no GroupNorm in between (a down-sampling convolution)
+    // optional: range[1] takes the running maximum of |output| as float bits -- the engine asks for it when the consumer runs on
+    // the fp16 matrix pipe with no GroupNorm in between (a down-sampling convolution; the attention core behind the qkv projection)
     int* range = nullptr;
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
@@ -135,7 +135,7 @@ hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, i
                           hipStream_t s, int* range = nullptr);  // range[1]: running max |output| as float bits (may be nullptr)
 
 // qkv: (B, 3C, N) channel-major [q | k | v]; out (B, C, N)
-hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s);
+hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, bool f16x2 = false);
 bool attention_supported(int C, int heads, int N);
 
 struct EmbedParams {

@@ -283,6 +283,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     const float* ru = p.res ? p.res + b * p.res_bs + (long)co_u * HW : nullptr;
     const float* bu = p.bias + co_u;
     constexpr int EPI_N = (MR * NR * 16 <= 64) ? NR : (NR / 2 > 0 ? NR / 2 : 1);
+    float amax = 0.f;
     double st_s[MR][4], st_q[MR][4];  // fp64: E[x^2]-E[x]^2 must not see fp32 roundoff; per 8-channel block
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -332,6 +333,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     if (p.scale) v *= sc;
                     const bool live = px_ok[j] && co_u + cu + 4 * hi < p.Cout;
                     if (live) (yu + (long)cu * HW)[loff[j]] = v;
+                    if (p.range && live) amax = fmaxf(amax, fabsf(v));
                     if (p.stat) {
                         const double vm = live ? (double)v : 0.0;
                         st_s[m][r >> 2] += vm;
@@ -340,6 +342,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 }
     }
     if (p.stat) epi_stat_write<WPX, MR>(p, st_s, st_q, b, th, tw, nTw, co_u, wave_px, lane);
+    if (p.range) {  // running max |output| (ConvParams::range), as in conv_epilogue_wide
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        const int bits = __float_as_int(amax);
+        if (lane == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
+    }
 }
 
 }  // namespace r2dm

@@ -37,12 +37,10 @@
 #include "common.h"
 #include "conv_bf16x3.h"
 #include "conv_epilogue.h"
+#include "f16x2.h"
 #include <stdlib.h>
 
 namespace r2dm {
-
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
 namespace f2 {
 using namespace x3;  // CO_T 64, TH 4, TW 64, XR 6, NG 2, CK 16, MR 2, NR 2
@@ -59,20 +57,7 @@ constexpr int RES0 = PATCH0 + 4 * 1024;                     // 104704: four wave
 constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;              // 153856: (a, d) of the current tile's sample, all Cin channels
 constexpr int ADTAB_BYTES = 4096;                           // Cin <= 512
 constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;             // 157952
-constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 }  // namespace f2
-
-// packed (h0, h1) and (l0, l1) of two fp32 values (low half = first value)
-__device__ __forceinline__ void split_f16x2(float v0, float v1, unsigned& ph, unsigned& pl) {
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);  // v_cvt_pk_f16_f32 (RNE)
-    // 2^11 (v - h), exact (a power-of-two scaling of an exact difference); written so that the fp16 -> fp32 conversion
-    // folds into v_fma_mix_f32: two instructions per value instead of three
-    const float r0 = __builtin_fmaf(-(float)h[0], f2::LSCALE, v0 * f2::LSCALE), r1 = __builtin_fmaf(-(float)h[1], f2::LSCALE, v1 * f2::LSCALE);
-    const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
-    ph = __builtin_bit_cast(unsigned, h);
-    pl = __builtin_bit_cast(unsigned, l);
-}
 
 template <int PRO>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles) {

@@ -416,7 +416,7 @@ struct Ctx {
     Tensor conv(const ConvLayer& L, const Src& x, int H, int W, int pro, const float2* aff, const Tensor* res,
                 size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0,
                 bool res_broadcast = false, bool input_bounded = false,  // input_bounded: its producer tracked max|x| in the range flag
-                bool track_out = false) {                               // track_out: record max|y| there (f16x2 launches only)
+                bool track_out = false) {                               // track_out: record max|y| there (precision mode 2 only)
         Tensor y;
         y.C = L.cout;
         y.H = H;
@@ -454,8 +454,8 @@ struct Ctx {
                 p.algo = ALGO_F16X2;
                 p.w = blob(L.w_f2);
                 p.co_tile = 64;
-                if (track_out) p.range = (int*)blob(h->range_flag);
             }
+            if (track_out && h->conv_pieces == 2 && p.algo != ALGO_DIRECT) p.range = (int*)blob(h->range_flag);
             if (fused_stats) {
                 p.stat = sink->p;
                 p.stat_G = h->cfg.gn_num_groups;
@@ -524,10 +524,13 @@ struct Ctx {
     // efficient_unet.py:42-53
     Tensor attention_block(const AttnLayer& a, const Tensor& x, const Sink& in_stats, const Sink* out, int out_goff) {
         float2* aff = norm(in_stats, src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
-        Tensor qkv = conv(a.qkv, src1(x), x.H, x.W, PRO_AFFINE, aff, nullptr, 0, false);
+        // precision mode 2: the attention core runs on the fp16 matrix pipe (attention.hip) and needs |q|, |k|, |v| < 65504: the
+        // projection's epilogue records max|qkv| in the range flag
+        const bool f2 = h->conv_pieces == 2;
+        Tensor qkv = conv(a.qkv, src1(x), x.H, x.W, PRO_AFFINE, aff, nullptr, 0, false, nullptr, nullptr, 0, false, false, f2);
         ar->release(aff);
         Tensor o = make(a.C, x.H, x.W);
-        if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st), "attention");
+        if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st, f2), "attention");
         drop(qkv);
         Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff);
         drop(o);
@@ -992,7 +995,7 @@ int r2dm_fir_up2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int3
 
 int r2dm_attention(const float* qkv, float* out, int32_t B, int32_t C, int32_t heads, int32_t N, void* stream) {
     if (!attention_supported(C, heads, N)) return fail(1, "attention: unsupported shape C=%d heads=%d N=%d", C, heads, N);
-    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream));
+    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream, g_single_kernel_pieces == 2));  // (per-op tests cover both)
     return 0;
 }
 

@@ -1,0 +1,33 @@
+// The exact 22-bit split of fp32 operands for the fp16 matrix pipe (conv_f16x2.hip, attention.hip):
+//   v = h + 2^-11 l,  h = RNE_f16(v),  l = RNE_f16(2^11 (v - h))
+// x w = xh wh + 2^-11 (xh wl + xl wh) + O(2^-22): three v_mfma_f32_32x32x16_f16, the xh wh products in one fp32 accumulator,
+// the cross products in a second one (scripts/probes/f16x2_probe.hip, profiles/r02_f16x2_probe.txt: more accurate on the
+// matrix pipe than three bf16 pieces / six products and than the fp32 MFMA).  Operands must fit the fp16 range (65504).
+#pragma once
+#include "common.h"
+
+namespace r2dm {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+namespace f2 {
+constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
+}
+
+// MODE.FP16_OVFL: f16 conversions of this wave saturate at +-65504 instead of producing inf
+__device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
+// packed (h0, h1) and (l0, l1) of two fp32 values (low half = first value)
+__device__ __forceinline__ void split_f16x2(float v0, float v1, unsigned& ph, unsigned& pl) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);  // v_cvt_pk_f16_f32 (RNE)
+    // 2^11 (v - h), exact (a power-of-two scaling of an exact difference); written so that the fp16 -> fp32 conversion
+    // folds into v_fma_mix_f32: two instructions per value instead of three
+    const float r0 = __builtin_fmaf(-(float)h[0], f2::LSCALE, v0 * f2::LSCALE), r1 = __builtin_fmaf(-(float)h[1], f2::LSCALE, v1 * f2::LSCALE);
+    const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+    ph = __builtin_bit_cast(unsigned, h);
+    pl = __builtin_bit_cast(unsigned, l);
+}
+
+}  // namespace r2dm

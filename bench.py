@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1, help="BASELINE.json configs[i] (see module docstring)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
+    ap.add_argument("--prewarm-s", type=float, default=1.0, help="seconds of untimed sampling before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "fp32-bf16x3"], default="fp32",
@@ -236,6 +237,13 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    # Clock pre-warm (untimed, before the W warm-up steps): an idle MI355X sits at 150 MHz and takes a few hundred
+    # milliseconds of load to reach the clock it then sustains; a short default run (16 steps = 0.13 s) measured from cold
+    # read 12 % low against the 256-step run of the same job (profiles/r02c).  This only changes the GPU's power state.
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < args.prewarm_s:
+        run(8)
+        torch.cuda.synchronize()
     run(max(args.warmup, 1))  # warm-up: W untimed steps (also sizes the workspace)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -302,7 +310,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cf["workload"] + f"; timed = one sample() call of --steps reverse steps, value scaled to {S} steps",
                        "baseline_config": args.config, "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
-                       "sampler": cf["mode"], "sampler_steps": S, "operand_split": args.precision,
+                       "sampler": cf["mode"], "sampler_steps": S, "operand_split": args.precision, "clock_prewarm_s": args.prewarm_s,
                        "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply on the matrix pipe "
                                      "with every fp32 operand split exactly -- fp16 + scaled fp16 residual (22 bits, 3 products, "
                                      "residual blocks) or three bf16 pieces (24 bits, 6 products, the other 3x3 convolutions" +

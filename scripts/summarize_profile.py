@@ -6,8 +6,9 @@ d, tag = sys.argv[1].rstrip('/') + '/', sys.argv[2]
 out = []
 rows = list(csv.DictReader(open(d + 'bench_kt_kernel_stats.csv')))
 jk = json.load(open(d + 'bench_kt.json'))
-nsteps = jk["steps"] + jk["warmup"] + min(jk["steps"], 4)  # timed + warm-up + the profiled pass
-out.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-torch-baseline   (1x MI355X, batch 8, {jk['warmup']} warm-up + {jk['steps']} timed + {min(jk['steps'], 4)} profiled steps = {nsteps} reverse steps)\n")
+nsteps = sum(int(r['Calls']) for r in rows if 'posterior_kernel' in r['Name'])  # one posterior update per reverse step
+out.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-torch-baseline   (1x MI355X, batch 8; {nsteps} reverse steps in the trace: "
+           f"~1 s clock pre-warm + {jk['warmup']} warm-up + {jk['steps']} timed + {min(jk['steps'], 4)} profiled)\n")
 out.append("%-86s %7s %9s %11s %10s %7s" % ("kernel", "calls", "per step", "total_ms", "avg_us", "pct"))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:22]:

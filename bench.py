@@ -325,6 +325,8 @@ def main():
             "traffic": pmc_traffic() if args.config == 1 else None,
             "peak_definition": "dominant kernel %s: dense 16-bit MFMA peak 2500 TF/s (2.4 GHz) / %d matrix products per algorithmic "
                                "fp32 product" % (dom["kernel"], dom.get("products_per_fp32_product", 1)),
+            "frac_of_round1_peak": dom["tflops"] / (PEAK_BF16 / 6 / 1e12),  # round 1 priced the same algorithmic FLOPs at 2500/6 = 416.7 TF/s
+            "frac_of_fp32_mfma_peak": dom["tflops"] * 1e12 / PEAK_FP32,
             "dominant_kernel": dom, "other_conv_kernels": conv[1:],
             "all_convs": {"tflops": sum(e["tflops"] * e["ms_per_step"] for e in conv) / sum(e["ms_per_step"] for e in conv),
                           "ms_per_step": sum(e["ms_per_step"] for e in conv), "launches_per_step": sum(e["launches_per_step"] for e in conv)},

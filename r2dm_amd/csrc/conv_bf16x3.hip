@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_stream_kernel(const ConvPa
     using namespace x3s;
     // COT = 64: every wave 64 co x 64 px (2 x 2 MFMA tiles).  COT = 32 (launches that would otherwise leave CUs idle):
     // 32 co x 64 px (1 x 2), half the MFMAs per tap under the same x tile, fragment and transform traffic.
-    // NPC = 3: exact three-piece split, six products (fp32-class error).  NPC = 2 (reduced-precision mode, SURVEY.md
-    // section 8 (f).3): two pieces = 16 mantissa bits per operand, three products, error ~2^-16 relative.
+    // NPC = 3: exact three-piece split, six products (fp32-class error).  (NPC = 2 -- two pieces, three products, ~2^-16 relative
+    // error -- was round 1's reduced-precision mode; it is no longer instantiated: conv_f16x2.hip does three products exactly.)
     constexpr int CO_T = COT, MR = COT / 32, NPROD = NPC == 3 ? 6 : 3, UNITS = NPROD * MR * NR, NFR = NPC * (MR + NR);
     constexpr int LPU = (12 + UNITS - 1) / UNITS;  // raw-load pieces per unit in tap 7
     static_assert(NPC == 3 || NPC == 2, "pieces");

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         b = __builtin_amdgcn_readfirstlane(t / nTh);
     };
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
-#ifdef F2_PROF  // timeline probe (scripts/spec_timeline.py): multiplier wave 0 and stager wave 4 of block 0 stamp s_memtime
+#ifdef F2_PROF  // timeline probe (scripts/f2_timeline.py): multiplier wave 0 and stager wave 4 of block 0 stamp s_memtime
     int prof_i = 0;
     auto stamp = [&](int code) __attribute__((always_inline)) {
         if (p.prof && blockIdx.x == 0 && wave == 0) {

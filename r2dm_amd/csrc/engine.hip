@@ -156,7 +156,11 @@ struct r2dm_handle {
         L.cin_pad = L.algo != ALGO_F32 ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
         L.w = take(L.packed_elems());
         // (at least half a wave of tiles per CU at the planned batch: below that the persistent kernel leaves CUs idle)
-        if (L.algo == ALGO_BF16X3 && H > 0 && conv_f16x2_supported(cin, cout, L.taps, H, W) && (px_batch / 256) * (cout / 64) >= 128) {
+        static const long f2_min_tiles = [] {  // (R2DM_F2_MIN_TILES: experiments)
+            const char* e = getenv("R2DM_F2_MIN_TILES");
+            return e ? atol(e) : 128L;
+        }();
+        if (L.algo == ALGO_BF16X3 && H > 0 && conv_f16x2_supported(cin, cout, L.taps, H, W) && (px_batch / 256) * (cout / 64) >= f2_min_tiles) {
             L.f2 = true;
             L.w_f2 = take((size_t)conv_f16x2_packed_floats(cin, cout));
         }

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         unsigned l_voff = 0;                         // this lane's byte offset inside a channel group's planes
         const unsigned l_avoff = (unsigned)s_g * 64;  // ... and inside a chunk's (a, d) pairs
         bool l_ok = false;
+        bool l_edge = false;  // (wave-uniform) the tile touches the top or bottom image row: some lanes' rows are zero padding
         auto set_load_item = [&](int it) __attribute__((always_inline)) {
             int cot, b, th, tw;
             decode(it, cot, b, th, tw);
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (gc >= W) gc -= W;  // azimuth is periodic
             const int gr = th * TH + s_row - 1;
             l_ok = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
+            l_edge = th == 0 || th == nTh - 1;
             l_voff = (unsigned)(s_g * 8 * HW + (l_ok ? gr * W + gc : 0)) * 4u;  // (16 HW floats < 2^31: launcher)
             l_x0 = p.x.p0 + b * p.x.bs0;
             l_x1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         struct RawSet {
             f32x4 raw[8];  // 8 channels x 4 pixels
             bool ok;       // row inside the image
+            bool edge;     // wave-uniform: the tile has padding rows at all (interior tiles skip the masking)
         };
         RawSet set0, set1;
         // The pixel loads are inline assembly, like the weight DMA: hipcc's own vmcnt bookkeeping cannot see the DMA, so a
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) gload(r.raw[i], xq + (size_t)i * HW * 4, l_voff);
             r.ok = l_ok;
+            r.edge = l_edge;
             if (l_c + 1 < nchunks)
                 ++l_c;
             else if (l_item + 1 < nIt) {
@@ -232,13 +236,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("" : "+v"(tab_v));
             if (tab_lane) *reinterpret_cast<f32x4*>(smem + ADTAB0 + t4 * 16) = tab_v;
         };
-        auto table_read = [&](bool ok) __attribute__((always_inline)) {  // this thread's 8 channels of chunk x_c
+        auto table_read = [&](bool ok, bool edge) __attribute__((always_inline)) {  // this thread's 8 channels of chunk x_c
             if (PRO == PRO_NONE) return;
             const int j0 = (x_c * CK + s_g * 8) >> 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
                 const f32x4 v = adtab[j0 + j];
-                ad4[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                ad4[j] = v;
+                if (edge) ad4[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
 
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 if (silu) { qv0 *= qm0; qv1 *= qm1; }
 #endif
             } else if (sl == 6) {
-                if (PRO == PRO_NONE) {
+                if (PRO == PRO_NONE && r.edge) {
                     qv0 = r.ok ? qv0 : 0.f;
                     qv1 = r.ok ? qv1 : 0.f;
                 }
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         // pixels 2*half, 2*half+1 of the thread's quad into x buffer `buf`
         auto transform_half = [&](RawSet& r, int half, unsigned char* buf, bool from_table = true) __attribute__((always_inline)) {
             float v0[2][4], v1[2][4], m0[2][4], m1[2][4];
-            if (half == 0 && from_table) table_read(r.ok);
+            if (half == 0 && from_table) table_read(r.ok, r.edge);
             // both pixels stage by stage: eight independent dependency chains (16 values) per stage -- the stager shares its
             // SIMD with a multiplier and cannot afford to wait for its own results (exp2 / rcp are quarter rate)
 #pragma unroll

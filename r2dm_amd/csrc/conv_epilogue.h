@@ -85,6 +85,42 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
 // 1: squares); after the scatter lane L holds the wave total of v = (L >> 3) & 7.  Groups of 8 / 16 / 32 channels lie
 // inside the half (slot half 0, zeros to half 1); a 64-channel group takes the two halves of its wave in slot halves
 // 0 and 1, exactly as two 32-channel tiles would.  Fixed summation order, every slot written exactly once per launch.
+// Cross-lane exchanges of the butterfly on the vector ALU (gfx950): v_permlane32_swap / v_permlane16_swap exchange the
+// upper 32 lanes (odd 16-lane rows) of one register with the lower 32 lanes (even rows) of another -- which IS one
+// reduce-scatter step for the pair (v[i], v[i + n]): after the swap P + Q holds v[i] summed over the partner in the lanes
+// that keep v[i] and v[i + n] in the lanes that keep v[i + n], without a select.  Steps inside a 16-lane row use DPP.  (The
+// ds_bpermute behind __shfl_xor goes through the LDS crossbar: ~120 cycles of latency per dependent step, ten steps and
+// two dwords per double -- 2 k of the multipliers' 8.5 k cycle epilogue in the round-2 timeline.)
+__device__ __forceinline__ void epi_swap_add(double& a, const double b, bool rows16) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if (rows16) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        a = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        a = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+}
+template <int CTRL>  // DPP control: 0xB1 quad_perm [1,0,3,2], 0x4E quad_perm [2,3,0,1], 0x141 row_half_mirror, 0x128 row_ror:8
+__device__ __forceinline__ double epi_dpp(const double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float epi_wave_max(float v) {  // all lanes end up with the wave's maximum (v >= 0)
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
 __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double (&st_s)[4], double (&st_q)[4], int b, int th,
                                                      int tw, int nTw, int co_half, int wave_px, int lane) {
     using gdouble = double __attribute__((address_space(1)))*;
@@ -94,24 +130,24 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
         v[2 * j] = st_s[j];
         v[2 * j + 1] = st_q[j];
     }
+    // scatter: lane bit 5, then 4, then 3 selects which half of the live values a lane keeps
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {  // scatter: the lane bit (32, 16, 8) selects which half of the live values a lane keeps
-        const int nv = 4 >> k, off = 32 >> k;
-        const bool up = lane & off;
+    for (int i = 0; i < 4; ++i) epi_swap_add(v[i], v[i + 4], false);
 #pragma unroll
-        for (int i = 0; i < nv; ++i) {
-            const double keep = up ? v[i + nv] : v[i], send = up ? v[i] : v[i + nv];
-            v[i] = keep + __shfl_xor(send, off, 64);
-        }
+    for (int i = 0; i < 2; ++i) epi_swap_add(v[i], v[i + 2], true);
+    {
+        const bool up = lane & 8;
+        const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + epi_dpp<0x128>(send);  // row_ror:8 = the lane 8 further on in the 16-lane row
     }
     double t = v[0];
-    t += __shfl_xor(t, 4, 64);
-    t += __shfl_xor(t, 2, 64);
-    t += __shfl_xor(t, 1, 64);
+    t += epi_dpp<0xB1>(t);   // the 8 lanes (4-pixel groups) of a channel row: pairs, quads, the other quad
+    t += epi_dpp<0x4E>(t);
+    t += epi_dpp<0x141>(t);
     // lane L: total of block k8 = (L >> 4) & 3, kind = (L >> 3) & 1; partners within a group differ in lane bits 4, 5
     const int bpg = p.stat_cpg >> 3;  // 1, 2, 4 or 8 blocks per group
-    if (bpg >= 2) t += __shfl_xor(t, 16, 64);
-    if (bpg >= 4) t += __shfl_xor(t, 32, 64);
+    if (bpg >= 2) epi_swap_add(t, t, true);    // + the lane 16 further on / back: blocks k8, k8 ^ 1
+    if (bpg >= 4) epi_swap_add(t, t, false);   // + the other 32 lanes: blocks k8, k8 ^ 2
     const int k8 = (lane >> 4) & 3, kind = (lane >> 3) & 1;
     const int bin = bpg < 4 ? bpg : 4;  // blocks of a group inside this half
     if ((lane & 7) == 0 && (k8 & (bin - 1)) == 0) {
@@ -171,12 +207,18 @@ __device__ __forceinline__ void conv_epilogue_prefetch_residual(const ConvParams
 // epilogues together, and 256 CUs reading 64 KiB each at that moment is an HBM burst the epilogue waits for (12 k of a 36 k
 // cycle tile in the round-2 timeline); prefetched during the MFMA phase the reads are free and only the stores remain,
 // which nobody waits for.
-template <int TH, int TW, int MR, int NR, bool ACC2, bool RES_AHEAD = false, int RES_LDS = 0>
+struct EpiNoStamp {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int TH, int TW, int MR, int NR, bool ACC2, bool RES_AHEAD = false, int RES_LDS = 0, class STAMP = EpiNoStamp>
 __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (&acc)[MR][NR],
                                                    f32x16 (&acc2)[ACC2 ? MR : 1][ACC2 ? NR : 1], int b, int th, int tw,
                                                    int nTw, int co_u, int wave_px, int lane, float* patch,
                                                    float acc2_scale = 1.0f,  // result = acc + acc2_scale * acc2
-                                                   const float* res_lds = nullptr) {
+                                                   const float* res_lds = nullptr,
+                                                   const float* bias_pre = nullptr,  // [MR][4]: this lane's biases, already requested
+                                                   const float* sc_pre = nullptr,    // ... and the output scale (conv_f16x2.hip)
+                                                   STAMP stamp = STAMP{}) {  // (timeline probe of conv_f16x2.hip)
     using gcf = const float __attribute__((address_space(1)))*;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
     using gf4 = f32x4 __attribute__((address_space(1)))*;
@@ -184,7 +226,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
     const int l31 = lane & 31, hi = lane >> 5;
     const int H = p.H, W = p.W, HW = H * W;
     const int tq_c = lane >> 3, tq_p = (lane & 7) * 4;  // after the turn: channel within the block, first of 4 pixels
-    const float sc = p.scale ? *p.scale : 1.0f;
+    const float sc = sc_pre ? *sc_pre : p.scale ? *p.scale : 1.0f;
     const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)co_u * HW);
     const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)co_u * HW);  // (only dereferenced if p.res)
     int loff[NR];  // in units of 4 floats
@@ -197,7 +239,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) bias[m][k8] = ((gcf)p.bias)[co_u + m * 32 + k8 * 8 + tq_c];
+        for (int k8 = 0; k8 < 4; ++k8) bias[m][k8] = bias_pre ? bias_pre[m * 4 + k8] : ((gcf)p.bias)[co_u + m * 32 + k8 * 8 + tq_c];
     constexpr int NQ = MR * NR;
     // residual values.  Default: the quarter being finished and the next one in flight (two buffers).  RES_AHEAD: all four
     // quarters are requested up front, into registers the caller has freed -- the epilogue waits for memory once.
@@ -209,6 +251,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
         }
     };
     float amax = 0.f;  // running max |output| (p.range)
+    stamp(20);
     if (RES_LDS == 0) load_q(0, 0, rv[0]);
     if (RES_AHEAD) {
 #pragma unroll
@@ -223,6 +266,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             const int q = m * NR + n;
+            if (q == 1) stamp(21);
             if (!RES_AHEAD && q + 1 < NQ) load_q((q + 1) / NR, (q + 1) % NR, rv[(q + 1) & 1]);
             f32x4 t[4];
 #pragma unroll
@@ -255,11 +299,12 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
                 }
             }
         }
+        stamp(22 + 2 * m);
         if (p.stat) epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, co_u + m * 32, wave_px, lane);
+        stamp(23 + 2 * m);
     }
     if (p.range) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = epi_wave_max(amax);
         const int bits = __float_as_int(amax);  // positive floats order like their bit patterns
         if (lane == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
     }

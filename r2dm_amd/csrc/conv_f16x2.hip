@@ -557,6 +557,20 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 // scratch) across the MFMA stream
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));
+                // bias and output scale are requested before anything else: their ~1.7 k cycles of latency used to be waited
+                // for in the middle of the first quarter; now the accumulator merge and the address arithmetic run under it.
+                // (this tile's residual prefetch was requested a whole tile ago: waiting for it first costs nothing and keeps
+                // the wait from covering the new loads)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                float bias_pre[MR * 4];
+                {
+                    using gcf = const float __attribute__((address_space(1)))*;
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) bias_pre[m * 4 + k8] = ((gcf)p.bias)[e_cot * CO_T + m * 32 + k8 * 8 + (lane_e >> 3)];
+                }
+                const float sc_pre = p.scale ? *(const float __attribute__((address_space(1)))*)p.scale : 1.0f;
                 // the two accumulators are combined first (acc + 2^-11 acl) and materialised: the second one's 64 registers then
                 // hold the residual tile, which the epilogue requests early (RES_AHEAD)
 #pragma unroll
@@ -568,10 +582,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 accd[1][1];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's residual prefetch (requested a tile ago) is in LDS
+#ifdef F2_PROF
+                auto estamp = [&](int c) __attribute__((always_inline)) { stamp(c); };
+                conv_epilogue_wide<TH, TW, MR, NR, false, true, RESQ, decltype(estamp)>(
+                    p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e, reinterpret_cast<float*>(smem + PATCH0) + wave * 256,
+                    1.0f, reinterpret_cast<const float*>(smem + RES0) + wave * (RESQ * 1024), bias_pre, &sc_pre, estamp);
+#else
                 conv_epilogue_wide<TH, TW, MR, NR, false, true, RESQ>(p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e,
                                                                       reinterpret_cast<float*>(smem + PATCH0) + wave * 256, 1.0f,
-                                                                      reinterpret_cast<const float*>(smem + RES0) + wave * (RESQ * 1024));
+                                                                      reinterpret_cast<const float*>(smem + RES0) + wave * (RESQ * 1024), bias_pre, &sc_pre);
+#endif
                 stamp(8);
                 // both accumulators restart from C = 0 in the next tile's first products; the compiler cannot see that the
                 // "accumulate" branch is never taken there and would keep all 128 registers alive across the epilogue: an

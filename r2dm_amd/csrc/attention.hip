@@ -13,6 +13,7 @@
 //                  two half-waves hold in register r -- no data movement between the two GEMMs.
 // fp32-in MFMA == fmaf chain, so this is plain fp32 attention numerically.
 #include "common.h"
+#include "wave_ops.h"
 #include "conv_bf16x3.h"
 #include "f16x2.h"
 
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             s[r] *= scale;
             mx = fmaxf(mx, s[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, wave_xor32(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             }
     }
     if (!active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + wave_xor32(l_run);
     const float inv = 1.0f / l_tot;
     float* op = out + ((long)b * C + (long)h * D) * N + q0 + l31;
 #pragma unroll
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
                 s[r] = fmaf(sl[r], f2::LINV, s[r]);
                 mx = fmaxf(mx, s[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, wave_xor32(mx));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __expf(m_run - m_new);
             float psum = 0.f;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
         __syncthreads();
     }
     if (!active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + wave_xor32(l_run);
     const float inv = 1.0f / l_tot;
     float* op = out + ((long)b * C + (long)h * D) * N + q0 + l31;
 #pragma unroll

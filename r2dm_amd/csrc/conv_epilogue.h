@@ -4,6 +4,7 @@
 // statistics of the output tensor (reference efficient_unet.py:95-110; ops.py:149-173).
 #pragma once
 #include "common.h"
+#include "wave_ops.h"
 
 namespace r2dm {
 
@@ -16,18 +17,20 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
     using gdouble = double __attribute__((address_space(1)))*;  // (global, not FLAT: flat stores also count on lgkmcnt)
     double bs[MR * 4], bq[MR * 4];
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int m = 0; m < MR; ++m) {
+        double v[8];
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
-            double a = st_s[m][k8], q = st_q[m][k8];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a += __shfl_xor(a, o, 64);
-                q += __shfl_xor(q, o, 64);
-            }
-            bs[m * 4 + k8] = a;
-            bq[m * 4 + k8] = q;
+            v[2 * k8] = st_s[m][k8];
+            v[2 * k8 + 1] = st_q[m][k8];
         }
+        wave_sum8(v, lane);
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            bs[m * 4 + k8] = v[2 * k8];
+            bq[m * 4 + k8] = v[2 * k8 + 1];
+        }
+    }
     if (lane == 0) {
         // Slots per (sample, group): two halves of S = stat_slots / 2, each with one slot per (pixel tile, pixel
         // wave).  A wave whose 32*MR channels contain whole groups writes its sums to half 0 and zeros to half 1; a
@@ -85,42 +88,6 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
 // 1: squares); after the scatter lane L holds the wave total of v = (L >> 3) & 7.  Groups of 8 / 16 / 32 channels lie
 // inside the half (slot half 0, zeros to half 1); a 64-channel group takes the two halves of its wave in slot halves
 // 0 and 1, exactly as two 32-channel tiles would.  Fixed summation order, every slot written exactly once per launch.
-// Cross-lane exchanges of the butterfly on the vector ALU (gfx950): v_permlane32_swap / v_permlane16_swap exchange the
-// upper 32 lanes (odd 16-lane rows) of one register with the lower 32 lanes (even rows) of another -- which IS one
-// reduce-scatter step for the pair (v[i], v[i + n]): after the swap P + Q holds v[i] summed over the partner in the lanes
-// that keep v[i] and v[i + n] in the lanes that keep v[i + n], without a select.  Steps inside a 16-lane row use DPP.  (The
-// ds_bpermute behind __shfl_xor goes through the LDS crossbar: ~120 cycles of latency per dependent step, ten steps and
-// two dwords per double -- 2 k of the multipliers' 8.5 k cycle epilogue in the round-2 timeline.)
-__device__ __forceinline__ void epi_swap_add(double& a, const double b, bool rows16) {
-    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
-    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-    if (rows16) {
-        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-        a = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    } else {
-        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-        a = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    }
-}
-template <int CTRL>  // DPP control: 0xB1 quad_perm [1,0,3,2], 0x4E quad_perm [2,3,0,1], 0x141 row_half_mirror, 0x128 row_ror:8
-__device__ __forceinline__ double epi_dpp(const double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float epi_wave_max(float v) {  // all lanes end up with the wave's maximum (v >= 0)
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
-}
-
 __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double (&st_s)[4], double (&st_q)[4], int b, int th,
                                                      int tw, int nTw, int co_half, int wave_px, int lane) {
     using gdouble = double __attribute__((address_space(1)))*;
@@ -130,24 +97,11 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
         v[2 * j] = st_s[j];
         v[2 * j + 1] = st_q[j];
     }
-    // scatter: lane bit 5, then 4, then 3 selects which half of the live values a lane keeps
-#pragma unroll
-    for (int i = 0; i < 4; ++i) epi_swap_add(v[i], v[i + 4], false);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) epi_swap_add(v[i], v[i + 2], true);
-    {
-        const bool up = lane & 8;
-        const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-        v[0] = keep + epi_dpp<0x128>(send);  // row_ror:8 = the lane 8 further on in the 16-lane row
-    }
-    double t = v[0];
-    t += epi_dpp<0xB1>(t);   // the 8 lanes (4-pixel groups) of a channel row: pairs, quads, the other quad
-    t += epi_dpp<0x4E>(t);
-    t += epi_dpp<0x141>(t);
+    double t = wave_sum8_scatter(v, lane);  // lane L: total of value (L >> 3) & 7 (wave_ops.h)
     // lane L: total of block k8 = (L >> 4) & 3, kind = (L >> 3) & 1; partners within a group differ in lane bits 4, 5
     const int bpg = p.stat_cpg >> 3;  // 1, 2, 4 or 8 blocks per group
-    if (bpg >= 2) epi_swap_add(t, t, true);    // + the lane 16 further on / back: blocks k8, k8 ^ 1
-    if (bpg >= 4) epi_swap_add(t, t, false);   // + the other 32 lanes: blocks k8, k8 ^ 2
+    if (bpg >= 2) wave_swap_add(t, t, true);    // + the lane 16 further on / back: blocks k8, k8 ^ 1
+    if (bpg >= 4) wave_swap_add(t, t, false);   // + the other 32 lanes: blocks k8, k8 ^ 2
     const int k8 = (lane >> 4) & 3, kind = (lane >> 3) & 1;
     const int bin = bpg < 4 ? bpg : 4;  // blocks of a group inside this half
     if ((lane & 7) == 0 && (k8 & (bin - 1)) == 0) {
@@ -304,7 +258,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
         stamp(23 + 2 * m);
     }
     if (p.range) {
-        amax = epi_wave_max(amax);
+        amax = wave_max_f32(amax);
         const int bits = __float_as_int(amax);  // positive floats order like their bit patterns
         if (lane == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
     }
@@ -388,8 +342,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
     if (p.stat) epi_stat_write<WPX, MR>(p, st_s, st_q, b, th, tw, nTw, co_u, wave_px, lane);
     if (p.range) {  // running max |output| (ConvParams::range), as in conv_epilogue_wide
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = wave_max_f32(amax);
         const int bits = __float_as_int(amax);
         if (lane == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
     }

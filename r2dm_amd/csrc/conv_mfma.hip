@@ -23,6 +23,7 @@
 // Accuracy: with ACC2 the accumulators are flushed into a second register set every 64 input
 // channels (576 products), so roundoff grows with sqrt(576) not sqrt(K) (K up to 4608).
 #include "common.h"
+#include "wave_ops.h"
 #include <stdlib.h>
 
 namespace r2dm {
@@ -424,18 +425,20 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
         // the wave in fp64, merge the blocks of a group, one slot per (pixel tile, pixel wave) -- fixed order.
         double bs[C::MR * 4], bq[C::MR * 4];
 #pragma unroll
-        for (int m = 0; m < C::MR; ++m)
+        for (int m = 0; m < C::MR; ++m) {
+            double v[8];
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) {
-                double a = st_s[m][k8], q = st_q[m][k8];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                bs[m * 4 + k8] = a;
-                bq[m * 4 + k8] = q;
+                v[2 * k8] = st_s[m][k8];
+                v[2 * k8 + 1] = st_q[m][k8];
             }
+            wave_sum8(v, lane);  // (wave_ops.h: butterfly on permlane swaps / DPP instead of 96 ds_bpermute)
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) {
+                bs[m * 4 + k8] = v[2 * k8];
+                bq[m * 4 + k8] = v[2 * k8 + 1];
+            }
+        }
         if (lane == 0) {
             const int bpg = p.stat_cpg >> 3;                 // 8-channel blocks per group
             const int slot = (th * nTw + tw) * 4 + wave_px;  // 4 slots per pixel tile (unused ones hold zeros)

@@ -7,17 +7,14 @@
 // projection matrices are packed row-wise into one [rows][T] matrix and evaluated in one launch.
 // The frequency table f_k is precomputed on the host with the reference's own expression.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace r2dm {
 
 // These vectors condition EVERY AdaGN layer (a common-mode error here is seen 24 times), and the whole kernel
 // is a few hundred KFLOP: accumulate in fp64 and use the accurate transcendental paths, so that the embedding
 // and the projections are correctly rounded fp32 values of the reference expressions.
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }  // (wave_ops.h)
 
 __device__ __forceinline__ float silu_exact(float v) {
     const double d = (double)v;

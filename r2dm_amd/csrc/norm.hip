@@ -12,16 +12,13 @@
 // (fp64 VALU is not a bottleneck on a streaming kernel and makes E[x^2]-E[x]^2 safe for groups of
 // up to 2^22 elements), wavefront shuffle reduce, fixed-order cross-block combine => deterministic.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace r2dm {
 
 constexpr int kGnThreads = 256;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }  // (wave_ops.h)
 
 // grid = (splits, G, B).  Group g of sample b = cpg consecutive planes (all inside one of the two
 // sources), i.e. n = cpg*HW contiguous floats; split s reduces elements [s*len, (s+1)*len).

@@ -8,6 +8,7 @@
 // W pass first, then H, like the reference's two depthwise convolutions (ops.py:131-132).
 // The FIR window is fixed: the host side refuses checkpoints whose `kernel` buffers differ.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace r2dm {
 
@@ -94,8 +95,7 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         }
     }
     if (range) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = wave_max_f32(amax);
         if ((threadIdx.x & 63) == 0) {
             const int bits = __float_as_int(amax);
             if (bits > __atomic_load_n(range + 1, __ATOMIC_RELAXED)) atomicMax(range + 1, bits);  // (rarely taken after the first blocks)

@@ -10,7 +10,7 @@ os.environ["R2DM_CONV_PROF_PTR"] = str(prof.data_ptr())
 from r2dm_amd import _lib
 from bench_conv_shapes import SHAPES
 L = _lib.lib(); st = torch.cuda.current_stream().cuda_stream
-NAMES = {1: "M arr#1", 2: "M arr#2", 3: "M arr#3", 4: "M lv#1", 5: "M lv#2", 6: "M lv#3", 7: "M epi begin", 8: "M epi end", 20: "M epi bias+res requested", 21: "M epi quarter 0 done", 22: "M epi m=0 quarters done", 23: "M epi m=0 stats written", 24: "M epi m=1 quarters done", 25: "M epi m=1 stats written",
+NAMES = {1: "M arr#1", 2: "M arr#2", 3: "M arr#3", 4: "M lv#1", 5: "M lv#2", 6: "M lv#3", 7: "M epi begin", 8: "M epi end", 20: "M epi bias+res requested", 26: "M epi accumulators merged", 27: "M epi residual requested", 28: "M epi q0 turned", 21: "M epi quarter 0 done", 22: "M epi m=0 quarters done", 23: "M epi m=0 stats written", 24: "M epi m=1 quarters done", 25: "M epi m=1 stats written",
          10: "h xf0 done", 11: "h arr#1", 12: "h lv#1", 13: "h xf1 done", 14: "h arr#2", 15: "h lv#2", 16: "h loads issued", 17: "h arr#3", 18: "h lv#3"}
 for n in os.environ.get("SHAPES", "L1_64_64").split(","):
     cin, cout, h, w, k, pro, res = SHAPES[n]

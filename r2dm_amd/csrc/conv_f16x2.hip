@@ -59,8 +59,16 @@ constexpr int ADTAB_BYTES = 4096;                           // Cin <= 512
 constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;             // 157952
 }  // namespace f2
 
+// Reciprocals for the tile decode (host: f2_magic): x / d == __umulhi(x, m) exactly for x * d < 2^32, m = floor(2^32 / d) + 1
+// (d == 1: m = 0, x / 1 = x).  The compiler's own signed 32-bit division is ~25 scalar instructions per quotient; a tile is
+// decoded four times (load cursor, weight cursor, table, epilogue), three of them by the stagers that bound the chunk time.
+struct F2Div {
+    unsigned co, tw, th;
+};
+static unsigned f2_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned long long)d) + 1u; }
+
 template <int PRO>
-__global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
     constexpr int UNITS = 3 * MR * NR, PPW = 3;   // 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager
     constexpr int NL = 8;                         // global loads per chunk of raw pixels (the folded affine comes from an LDS table)
@@ -88,16 +96,15 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     const int Q = nIt * nchunks;
     const int c0 = p.x.c0;
 
-    // tile `it` of this block -> output channel tile, sample, tile row / column.  Integer division runs on the vector ALU:
-    // tell the compiler the results are wave-uniform, or every address derived from them becomes per-lane 64-bit arithmetic.
+    // tile `it` of this block -> output channel tile, sample, tile row / column (all wave-uniform: scalar ALU, F2Div)
+    auto udiv = [&](unsigned x, int d, unsigned m) __attribute__((always_inline)) { return d == 1 ? x : __umulhi(x, m); };
     auto decode = [&](int it, int& cot, int& b, int& th, int& tw) __attribute__((always_inline)) {
-        const int L = xcd_remap((int)blockIdx.x + it * G, total_tiles);
-        cot = __builtin_amdgcn_readfirstlane(L % nCoT);
-        int t = L / nCoT;
-        tw = __builtin_amdgcn_readfirstlane(t % nTw);
-        t /= nTw;
-        th = __builtin_amdgcn_readfirstlane(t % nTh);
-        b = __builtin_amdgcn_readfirstlane(t / nTh);
+        const unsigned L = (unsigned)__builtin_amdgcn_readfirstlane(xcd_remap((int)blockIdx.x + it * G, total_tiles));
+        const unsigned t1 = udiv(L, nCoT, dv.co), t2 = udiv(t1, nTw, dv.tw), t3 = udiv(t2, nTh, dv.th);
+        cot = (int)(L - t1 * (unsigned)nCoT);
+        tw = (int)(t1 - t2 * (unsigned)nTw);
+        th = (int)(t2 - t3 * (unsigned)nTh);
+        b = (int)t3;
     };
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
 #ifdef F2_PROF  // timeline probe (scripts/f2_timeline.py): multiplier wave 0 and stager wave 4 of block 0 stamp s_memtime
@@ -692,7 +699,11 @@ static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
     }
     const int n_cu = f2_cu_count();
     const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2::LDS_TOTAL, s, p, (int)tiles);
+    const int nCoT = p.Cout / f2::CO_T, nTw = p.W / f2::TW, nTh = p.H / f2::TH;
+    const int dmax = nCoT > nTw ? (nCoT > nTh ? nCoT : nTh) : (nTw > nTh ? nTw : nTh);
+    if (tiles * dmax >= (1ll << 32)) return hipErrorInvalidValue;  // (F2Div is exact below that)
+    const F2Div dv{f2_magic(nCoT), f2_magic(nTw), f2_magic(nTh)};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2::LDS_TOTAL, s, p, (int)tiles, dv);
     return hipGetLastError();
 }
 

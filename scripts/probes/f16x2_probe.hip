@@ -22,7 +22,8 @@ __device__ inline float bf16_round(float v) {  // RNE to bf16, returned as float
     return __uint_as_float(u);
 }
 // mode 0: bf16x3, 1: f16x2 hi/lo, 2: f16x2 hi/lo with the sign pattern (blocks of 32 k negated, accumulators flipped), 3: f32 MFMA,
-// 4: f16x2 single accumulator (unscaled residuals)
+// 4: f16x2 single accumulator (unscaled residuals), 5: single accumulator, the B operand (weights) pre-scaled by 2^13 so that its
+// residual is a normal fp16 number, the A residual unscaled (subnormal below |a| ~ 0.25); result scaled back by 2^-13
 __global__ void probe(const float* A, const float* B, float* C, int K, int mode) {
     const int lane = threadIdx.x, r32 = lane & 31, hi = lane >> 5;
     f32x16 acc = {0}, lo = {0};
@@ -42,15 +43,15 @@ __global__ void probe(const float* A, const float* B, float* C, int K, int mode)
             }
             const int PI[6] = {2, 0, 1, 1, 0, 0}, PJ[6] = {0, 2, 1, 0, 1, 0};
             for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PI[q]], bp[PJ[q]], acc, 0, 0, 0);
-        } else if (mode == 1 || mode == 2 || mode == 4) {
+        } else if (mode == 1 || mode == 2 || mode == 4 || mode == 5) {
             f16x8 a0, a1, b0, b1;
             for (int i = 0; i < 8; ++i) {
-                const float bb = neg ? -b[i] : b[i];
+                const float bb = (neg ? -b[i] : b[i]) * (mode == 5 ? 8192.f : 1.f);
                 a0[i] = (_Float16)a[i]; b0[i] = (_Float16)bb;
-                const float sc = mode == 4 ? 1.f : S;
+                const float sc = (mode == 4 || mode == 5) ? 1.f : S;
                 a1[i] = (_Float16)((a[i] - (float)a0[i]) * sc); b1[i] = (_Float16)((bb - (float)b0[i]) * sc);
             }
-            if (mode == 4) {
+            if (mode == 4 || mode == 5) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
@@ -71,6 +72,7 @@ __global__ void probe(const float* A, const float* B, float* C, int K, int mode)
         const int row = (r / 4) * 8 + hi * 4 + (r % 4), col = r32;
         float v = acc[r];
         if (mode == 1 || mode == 2) v = acc[r] + lo[r] * (1.f / 2048.f);
+        if (mode == 5) v *= 1.f / 8192.f;
         C[row * 32 + col] = v;
     }
 }
@@ -78,7 +80,7 @@ __global__ void probe(const float* A, const float* B, float* C, int K, int mode)
 int main() {
     std::mt19937_64 g(1);
     std::normal_distribution<double> nd(0, 1);
-    const char* names[5] = {"bf16x3", "f16x2 hi/lo", "f16x2 hi/lo +signs", "f32 mfma", "f16x2 single unscaled"};
+    const char* names[6] = {"bf16x3", "f16x2 hi/lo", "f16x2 hi/lo +signs", "f32 mfma", "f16x2 single unscaled", "f16x2 single, weights x 2^13"};
     for (int tiny = 0; tiny < 2; ++tiny)
         for (int K : {576, 1152, 4608}) {
             std::vector<float> A(32 * K), B(K * 32), C(32 * 32);
@@ -91,7 +93,7 @@ int main() {
             CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, C.size() * 4));
             CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
             printf("K=%d %s:", K, tiny ? "(quarter of the operands scaled by 1e-5 / 1e-4)" : "");
-            for (int mode = 0; mode < 5; ++mode) {
+            for (int mode = 0; mode < 6; ++mode) {
                 hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dA, dB, dC, K, mode);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));

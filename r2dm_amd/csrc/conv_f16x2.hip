@@ -50,9 +50,9 @@ constexpr int XPL = NG * XR * XS;                           // 16-byte entries p
 constexpr int XBYTES = NPL * XPL * 16;                      // 25728
 constexpr int WSTAGE = NPL * 3 * NG * CO_T * 16;            // 12288: one kernel row of one chunk
 constexpr int RING = 4;
-constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches][residual][(a, d) table]
+constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches][finished tile][(a, d) table]
 constexpr int PATCH0 = WB0 + RING * WSTAGE;                 // 100608
-constexpr int RESQ = 3;                                     // quarters of the residual tile prefetched into LDS (of 4)
+constexpr int RESQ = 3;                                     // quarters of a finished tile that wait in LDS for their deferred epilogue (of 4)
 constexpr int RES0 = PATCH0 + 4 * 1024;                     // 104704: four waves x RESQ x 4 KiB
 constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;              // 153856: (a, d) of the current tile's sample, all Cin channels
 constexpr int ADTAB_BYTES = 4096;                           // Cin <= 512
@@ -549,68 +549,164 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     };
     int e_item = 0, e_cot, e_b, e_th, e_tw;
     decode(0, e_cot, e_b, e_th, e_tw);
+
+    // ---- epilogue: one quarter of the tile (32 channels x 32 pixels per wave) at the tile's end, the other three at the next
+    // tile's first three chunk boundaries.  The multipliers are not what bounds a chunk (the stagers are, by ~0.7 k cycles), so
+    // a quarter (~1.2 k cycles) behind a chunk costs the chunk ~0.5 k -- against ~10 k cycles of epilogue + refill per tile with
+    // the matrix pipe idle when all four quarters ran at the tile's end.  The finished tile waits in LDS, already "turned"
+    // (conv_epilogue.h: 4 consecutive pixels of one channel per lane) in the 48 KiB that used to hold the prefetched residual;
+    // the residual now comes straight from global memory, each quarter requested one chunk before it is added (16 registers).
+    using gcf = const float __attribute__((address_space(1)))*;
+    using gcf4 = const f32x4 __attribute__((address_space(1)))*;
+    using gf4 = f32x4 __attribute__((address_space(1)))*;
+    constexpr int SEGW = TW / 32, NQ = MR * NR;
+    static_assert(NQ == 4 && RESQ == 3, "three deferred quarters in the former residual area");
+    float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
+    f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
+    float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
+    float amax_e = 0.f;
+    int pe_b = 0, pe_th = 0, pe_tw = 0, pe_cot = 0;
+    bool pending = false;
+    const float sc_blk = p.scale ? *(gcf)p.scale : 1.0f;
+    float* const dump = reinterpret_cast<float*>(smem + RES0) + wave * (RESQ * 1024);
+    float* const patch = reinterpret_cast<float*>(smem + PATCH0) + wave * 256;
+    auto fresh_lane = [&]() __attribute__((always_inline)) {  // (per-lane constants must not be hoisted across the MFMA stream)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
+    auto res_request = [&](auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) {
+        if (!p.res) return;
+        constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
+        const int s = wave * NR + n;
+        const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
+        const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)(cot * CO_T) * HW);
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) rv_e[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
+    };
+    // the turn: this wave's accumulator quarter (m, n) -> dst[8-channel block][8 channels][32 pixels]
+    auto turn_write = [&](auto QD, float* dst, int ln) __attribute__((always_inline)) {
+        constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
+        const int l31e = ln & 31, hie = ln >> 5;
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[k8 * 256 + (j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
+    };
+    // bias, residual, scale, store, statistics of one turned quarter (t[k8]: 4 consecutive pixels of channel 8 k8 + lane / 8)
+    auto quarter = [&](auto QD, const f32x4 (&t)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+        constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
+        const int s = wave * NR + n;
+        const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
+        const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)(cot * CO_T) * HW);
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            f32x4 v = t[k8] + bias_e[m * 4 + k8];
+            if (p.res) v = rv_e[k8] + v;
+            v *= sc_blk;  // (1.0f without p.scale: exact)
+            (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
+            if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);
+            pq[k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+        }
+    };
+    auto half_stats = [&](auto M, const float (&s0)[4], const float (&q0)[4], const float (&s1)[4], const float (&q1)[4], int b, int th,
+                          int tw, int cot, int ln) __attribute__((always_inline)) {
+        if (!p.stat) return;
+        double st_s[4], st_q[4];
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {  // (four pixels in fp32, fp64 beyond: conv_epilogue.h)
+            st_s[k8] = (double)s0[k8] + (double)s1[k8];
+            st_q[k8] = (double)q0[k8] + (double)q1[k8];
+        }
+        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * CO_T + decltype(M)::value * 32, wave, ln);
+    };
+    auto range_flush = [&](int ln) __attribute__((always_inline)) {
+        if (!p.range) return;
+        const float a = wave_max_f32(amax_e);
+        const int bits = __float_as_int(a);  // positive floats order like their bit patterns
+        if (ln == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
+        amax_e = 0.f;
+    };
+    // deferred quarter S (1..3) of the pending tile
+    auto slice = [&](auto SS) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;
+        const int ln = fresh_lane();
+        f32x4 t[4];
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + (S - 1) * 1024 + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
+        float ps[4], pq[4];
+        quarter(SS, t, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq);
+        if (S < 3) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
+        if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
+        if (S == 2) {
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) { cs[k8] = ps[k8]; cq[k8] = pq[k8]; }
+        }
+        if (S == 3) {
+            half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
+            range_flush(ln);
+            pending = false;
+        }
+    };
+
     auto chunk = [&](int q, auto PAR) __attribute__((always_inline)) {
+        if constexpr (decltype(PAR)::value == 1) {
+            if (e_c == nchunks - 1) {  // the tile's last chunk: its biases and the first quarter's residual are requested now
+                const int ln = fresh_lane();
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = ((gcf)p.bias)[e_cot * CO_T + m * 32 + k8 * 8 + (ln >> 3)];
+                res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
+            }
+        }
         tap(q, ic<0>{}, PAR); tap(q, ic<1>{}, PAR); tap(q, ic<2>{}, PAR);
         tap(q, ic<3>{}, PAR); tap(q, ic<4>{}, PAR); tap(q, ic<5>{}, PAR);
         tap(q, ic<6>{}, PAR); tap(q, ic<7>{}, PAR); tap(q, ic<8>{}, PAR);
         ++e_c;
-        if constexpr (decltype(PAR)::value == 1) {  // (tiles end on odd chunks)
+        if constexpr (decltype(PAR)::value == 0) {
+            if (pending && e_c == 1) slice(ic<1>{});
+            if (pending && e_c == 3) slice(ic<3>{});
+        } else {
+            if (pending && e_c == 2) slice(ic<2>{});
             if (e_c == nchunks) {  // tile finished
                 e_c = 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
                 stamp(7);
-                // the epilogue's per-lane constants (patch addresses, butterfly selectors, ...) are recomputed here from a lane
-                // id the compiler cannot trace: hoisted out of the tile loop they would have to live in registers (or
-                // scratch) across the MFMA stream
-                int lane_e = lane;
-                asm volatile("" : "+v"(lane_e));
-                // bias and output scale are requested before anything else: their ~1.7 k cycles of latency used to be waited
-                // for in the middle of the first quarter; now the accumulator merge and the address arithmetic run under it.
-                // (this tile's residual prefetch was requested a whole tile ago: waiting for it first costs nothing and keeps
-                // the wait from covering the new loads)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                float bias_pre[MR * 4];
-                {
-                    using gcf = const float __attribute__((address_space(1)))*;
-#pragma unroll
-                    for (int m = 0; m < MR; ++m)
-#pragma unroll
-                        for (int k8 = 0; k8 < 4; ++k8) bias_pre[m * 4 + k8] = ((gcf)p.bias)[e_cot * CO_T + m * 32 + k8 * 8 + (lane_e >> 3)];
-                }
-                const float sc_pre = p.scale ? *(const float __attribute__((address_space(1)))*)p.scale : 1.0f;
-                // the two accumulators are combined first (acc + 2^-11 acl) and materialised: the second one's 64 registers then
-                // hold the residual tile, which the epilogue requests early (RES_AHEAD)
+                const int ln = fresh_lane();
+                // the two accumulators are combined (acc + 2^-11 acl)
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int n = 0; n < NR; ++n)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][n][r] = __builtin_fmaf(acl[m][n][r], LINV, acc[m][n][r]);
-                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                f32x16 accd[1][1];
-#ifdef F2_PROF
-                auto estamp = [&](int c) __attribute__((always_inline)) { stamp(c); };
-                conv_epilogue_wide<TH, TW, MR, NR, false, true, RESQ, decltype(estamp)>(
-                    p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e, reinterpret_cast<float*>(smem + PATCH0) + wave * 256,
-                    1.0f, reinterpret_cast<const float*>(smem + RES0) + wave * (RESQ * 1024), bias_pre, &sc_pre, estamp);
-#else
-                conv_epilogue_wide<TH, TW, MR, NR, false, true, RESQ>(p, acc, accd, e_b, e_th, e_tw, nTw, e_cot * CO_T, wave, lane_e,
-                                                                      reinterpret_cast<float*>(smem + PATCH0) + wave * 256, 1.0f,
-                                                                      reinterpret_cast<const float*>(smem + RES0) + wave * (RESQ * 1024), bias_pre, &sc_pre);
-#endif
+                // quarter 0 right away (through the 1 KiB patch, block by block), quarters 1..3 into the LDS area
+                {
+                    f32x4 t[4];
+                    const int l31e = ln & 31, hie = ln >> 5;
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) patch[(j + 4 * hie) * 32 + l31e] = acc[0][0][4 * k8 + j];
+                        t[k8] = *reinterpret_cast<const f32x4*>(patch + (ln >> 3) * 32 + (ln & 7) * 4);
+                    }
+                    turn_write(ic<1>{}, dump, ln);
+                    turn_write(ic<2>{}, dump + 1024, ln);
+                    turn_write(ic<3>{}, dump + 2048, ln);
+                    quarter(ic<0>{}, t, e_b, e_th, e_tw, e_cot, ln, cs, cq);
+                    res_request(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
+                }
+                pe_b = e_b; pe_th = e_th; pe_tw = e_tw; pe_cot = e_cot;
+                pending = true;
                 stamp(8);
                 // both accumulators restart from C = 0 in the next tile's first products; the compiler cannot see that the
-                // "accumulate" branch is never taken there and would keep all 128 registers alive across the epilogue: an
-                // empty definition ends the old values' lives (no instruction)
+                // "accumulate" branch is never taken there and would keep all 128 registers alive: an empty definition ends
+                // the old values' lives (no instruction)
                 asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
                 asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
-                if (++e_item < nIt) {
-                    decode(e_item, e_cot, e_b, e_th, e_tw);
-                    // the next tile's residual: three quarters by LDS-DMA now, consumed a whole tile later
-                    conv_epilogue_prefetch_residual<TH, TW, MR, NR, RESQ>(p, e_b, e_th, e_tw, e_cot * CO_T, wave, lane_e,
-                                                                          lds0 + RES0 + (unsigned)(wave * (RESQ * 4096)));
-                }
+                if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
                 // first fragments of the next tile (its chunk 0 sits in x buffer 0, stage 3(q+1) in the ring: published at
                 // this chunk's last barrier); also after the last tile -- harmless, keeps the registers plainly defined
                 frag_first(lds_w0 + (unsigned)(((3 * (q + 1)) & (RING - 1)) * WSTAGE));
@@ -618,13 +714,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         }
     };
 
-    conv_epilogue_prefetch_residual<TH, TW, MR, NR, RESQ>(p, e_b, e_th, e_tw, e_cot * CO_T, wave, lane, lds0 + RES0 + (unsigned)(wave * (RESQ * 4096)));
     __builtin_amdgcn_s_barrier();  // P: ring stages 0..RING-2 and chunk 0 staged
     asm volatile("" ::: "memory");
     frag_first(lds_w0);
     for (int q = 0; q < Q; q += 2) {  // (Q is even: Cin % 32 == 0)
         chunk(q, ic<0>{});
         chunk(q + 1, ic<1>{});
+    }
+    if (pending) {  // the last tile's deferred quarters
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slice(ic<1>{});
+        slice(ic<2>{});
+        slice(ic<3>{});
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // prefetched fragments must not outlive the block
     stamp_real(1);

@@ -115,33 +115,6 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
     }
 }
 
-// LDS-DMA of the first NQL quarters of a tile's residual into this wave's LDS area (byte address lds_dst; 4 KiB per
-// quarter): lane i of request (q, k8) fetches exactly the 16 bytes conv_epilogue_wide's lane i adds in that quarter and
-// block.  No registers are held; completion is the issuing wave's vmcnt.
-template <int TH, int TW, int MR, int NR, int NQL>
-__device__ __forceinline__ void conv_epilogue_prefetch_residual(const ConvParams& p, int b, int th, int tw, int co_u, int wave_px,
-                                                                int lane, unsigned lds_dst) {
-    constexpr int SEGW = TW / 32;
-    if (!p.res) return;
-    const int HW = p.H * p.W;
-    const int tq_c = lane >> 3, tq_p = (lane & 7) * 4;
-    const float* ru = p.res + b * p.res_bs + (long)co_u * HW;
-#pragma unroll
-    for (int q = 0; q < NQL; ++q) {
-        const int m = q / NR, n = q % NR, s = wave_px * NR + n;
-        const long off = (long)tq_c * HW + (th * TH + s / SEGW) * p.W + tw * TW + (s % SEGW) * 32 + tq_p;
-#pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) {
-            const float* src = ru + (long)(m * 32 + k8 * 8) * HW + off;
-            unsigned keep;  // M0 = wave-uniform LDS base of the 1 KiB request; lane i lands at base + 16 i
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src), "s"(lds_dst + (unsigned)((q * 4 + k8) * 1024))
-                         : "memory");
-        }
-    }
-}
-
 // ---- wide epilogue (whole tiles: H % TH == 0, W % TW == 0, Cout % (32 MR) == 0) --------------------------------------
 // The MFMA layout gives a lane ONE pixel of 16 channels, i.e. 4-byte global accesses, 256 B per instruction -- and a CU
 // retires those at a few bytes per cycle (in-kernel timeline of round 2: the residual loads + stores of one 64 x 256 tile
@@ -153,26 +126,12 @@ __device__ __forceinline__ void conv_epilogue_prefetch_residual(const ConvParams
 // reduce-scatter per 32-channel half (epi_stat_write_bfly8).
 // Explicit global address space everywhere: a pointer that reaches a load through a phi is otherwise accessed with FLAT
 // instructions, which count on lgkmcnt as well and turn every LDS wait into a wait for HBM.
-// RES_AHEAD: all residual quarters are requested up front (64 registers: callers whose accumulators leave room, i.e.
-// conv_f16x2.hip after its two accumulators have been combined) instead of one quarter ahead.
-// RES_LDS > 0: the first RES_LDS quarters of the residual tile already sit in LDS (`res_lds`: this wave's area, laid out
-// [quarter][8-channel block][lane] x 16 bytes by conv_epilogue_prefetch_residual, which the caller issued a whole tile
-// earlier and has waited for); the remaining quarters are loaded here.  Why: a persistent kernel's blocks reach their
-// epilogues together, and 256 CUs reading 64 KiB each at that moment is an HBM burst the epilogue waits for (12 k of a 36 k
-// cycle tile in the round-2 timeline); prefetched during the MFMA phase the reads are free and only the stores remain,
-// which nobody waits for.
-struct EpiNoStamp {
-    __device__ __forceinline__ void operator()(int) const {}
-};
-template <int TH, int TW, int MR, int NR, bool ACC2, bool RES_AHEAD = false, int RES_LDS = 0, class STAMP = EpiNoStamp>
+// conv_f16x2.hip has its own arrangement of the same steps (one quarter at the tile's end, three deferred into the next tile).
+template <int TH, int TW, int MR, int NR, bool ACC2>
 __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (&acc)[MR][NR],
                                                    f32x16 (&acc2)[ACC2 ? MR : 1][ACC2 ? NR : 1], int b, int th, int tw,
                                                    int nTw, int co_u, int wave_px, int lane, float* patch,
-                                                   float acc2_scale = 1.0f,  // result = acc + acc2_scale * acc2
-                                                   const float* res_lds = nullptr,
-                                                   const float* bias_pre = nullptr,  // [MR][4]: this lane's biases, already requested
-                                                   const float* sc_pre = nullptr,    // ... and the output scale (conv_f16x2.hip)
-                                                   STAMP stamp = STAMP{}) {  // (timeline probe of conv_f16x2.hip)
+                                                   float acc2_scale = 1.0f) {  // result = acc + acc2_scale * acc2
     using gcf = const float __attribute__((address_space(1)))*;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
     using gf4 = f32x4 __attribute__((address_space(1)))*;
@@ -180,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
     const int l31 = lane & 31, hi = lane >> 5;
     const int H = p.H, W = p.W, HW = H * W;
     const int tq_c = lane >> 3, tq_p = (lane & 7) * 4;  // after the turn: channel within the block, first of 4 pixels
-    const float sc = sc_pre ? *sc_pre : p.scale ? *p.scale : 1.0f;
+    const float sc = p.scale ? *p.scale : 1.0f;
     const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)co_u * HW);
     const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)co_u * HW);  // (only dereferenced if p.res)
     int loff[NR];  // in units of 4 floats
@@ -193,11 +152,10 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) bias[m][k8] = bias_pre ? bias_pre[m * 4 + k8] : ((gcf)p.bias)[co_u + m * 32 + k8 * 8 + tq_c];
+        for (int k8 = 0; k8 < 4; ++k8) bias[m][k8] = ((gcf)p.bias)[co_u + m * 32 + k8 * 8 + tq_c];
     constexpr int NQ = MR * NR;
-    // residual values.  Default: the quarter being finished and the next one in flight (two buffers).  RES_AHEAD: all four
-    // quarters are requested up front, into registers the caller has freed -- the epilogue waits for memory once.
-    f32x4 rv[RES_AHEAD ? NQ : 2][4];
+    // residual values: the quarter being finished and the next one in flight (two buffers)
+    f32x4 rv[2][4];
     auto load_q = [&](int m, int n, f32x4 (&r)[4]) __attribute__((always_inline)) {
         if (p.res) {
 #pragma unroll
@@ -205,13 +163,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
         }
     };
     float amax = 0.f;  // running max |output| (p.range)
-    stamp(20);
-    if (RES_LDS == 0) load_q(0, 0, rv[0]);
-    if (RES_AHEAD) {
-#pragma unroll
-        for (int q = (RES_LDS > 1 ? RES_LDS : 1); q < NQ; ++q) load_q(q / NR, q % NR, rv[q]);
-    }
-    static_assert(RES_LDS == 0 || RES_AHEAD, "RES_LDS builds on RES_AHEAD");
+    load_q(0, 0, rv[0]);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         double st_s[4], st_q[4];
@@ -220,8 +172,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             const int q = m * NR + n;
-            if (q == 1) stamp(21);
-            if (!RES_AHEAD && q + 1 < NQ) load_q((q + 1) / NR, (q + 1) % NR, rv[(q + 1) & 1]);
+            if (q + 1 < NQ) load_q((q + 1) / NR, (q + 1) % NR, rv[(q + 1) & 1]);
             f32x4 t[4];
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) {  // the four blocks through the patch back to back (in-order LDS: no waits between)
@@ -236,12 +187,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) {
                 f32x4 v = t[k8] + bias[m][k8];
-                if (p.res) {
-                    if (q < RES_LDS)
-                        v = *reinterpret_cast<const f32x4*>(res_lds + ((q * 4 + k8) * 64 + lane) * 4) + v;
-                    else
-                        v = rv[RES_AHEAD ? q : q & 1][k8] + v;
-                }
+                if (p.res) v = rv[q & 1][k8] + v;
                 if (p.scale) v *= sc;
                 (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]] = v;
                 if (p.range) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -253,9 +199,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
                 }
             }
         }
-        stamp(22 + 2 * m);
         if (p.stat) epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, co_u + m * 32, wave_px, lane);
-        stamp(23 + 2 * m);
     }
     if (p.range) {
         amax = wave_max_f32(amax);

@@ -282,6 +282,23 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
             rows.append(memo[key][1])
         return torch.cat(conds), torch.stack(rows).contiguous(), (_M_CT_DDPM if mode == "ddpm" else _M_CT_DDIM)
 
+    def _sample_tables(self, num_steps: int, batch_size: int, mode: str, ddim_eta: float, dev):
+        """(cond (S, B), coef (S, B, 8), kernel mode) of a whole ``sample`` call on the device.  The table is a pure function of
+        the schedule and the step count; evaluating it row by row on the host (see ``_coefficients``) costs ~40 ms for 256
+        steps with the GPU idle, so the last few are kept (the reference recomputes its scalars inside every step)."""
+        key = (num_steps, batch_size, mode, float(ddim_eta), str(dev), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high)
+        cache = self.__dict__.setdefault("_tables", {})
+        hit = cache.get(key)
+        if hit is None:
+            steps = torch.linspace(1.0, 0.0, num_steps + 1)
+            cond, coef, mode_id = self._coefficients(steps[:-1], steps[1:], mode, ddim_eta)
+            cond = cond[:, None].expand(num_steps, batch_size).contiguous().to(dev)
+            coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            hit = cache[key] = (cond, coef, mode_id)
+        return hit
+
     @torch.inference_mode()
     def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
@@ -302,10 +319,7 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=dev)
         if return_all:
             out = [x]
-        steps = torch.linspace(1.0, 0.0, num_steps + 1)
-        cond, coef, mode_id = self._coefficients(steps[:-1], steps[1:], mode, ddim_eta)
-        cond = cond[:, None].expand(num_steps, batch_size).contiguous().to(dev)
-        coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
+        cond, coef, mode_id = self._sample_tables(num_steps, batch_size, mode, ddim_eta, dev)
         with _range_guard(self.model):
             for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
                 prediction = self.model(x, cond[i])

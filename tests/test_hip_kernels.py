@@ -37,7 +37,8 @@ def sd(O):
 # spatial size reduced 4x per axis where the full map would take the CPU oracle too long
 CONV3 = [(34, 64, 16, 256), (64, 64, 16, 256), (64, 128, 16, 256), (128, 64, 16, 256), (64, 2, 16, 256),
          (128, 128, 8, 128), (128, 256, 8, 128), (256, 64, 8, 128), (256, 256, 16, 256), (256, 512, 4, 64),
-         (512, 128, 4, 64), (512, 512, 8, 128), (512, 256, 8, 128), (40, 72, 12, 96), (64, 64, 2, 16)]
+         (512, 128, 4, 64), (512, 512, 8, 128), (512, 256, 8, 128), (40, 72, 12, 96), (64, 64, 2, 16),
+         (16, 3, 7, 36), (64, 4, 9, 260)]  # few-output (direct) kernel: odd heights, widths that are not a multiple of its 256-column block
 
 
 @pytest.mark.parametrize("cin,cout,h,w", CONV3)

@@ -94,6 +94,7 @@ hipError_t launch_pack_conv(const float* w_oihw, float* dst, int Cout, int Cin, 
                             int cin_pad, hipStream_t s, int algo = ALGO_F32, int src_cin = 0, int src_off = 0);
 bool conv_bf16x3_supported(int Cin, int Cout, int taps);
 bool conv_direct_supported(int Cout, int taps);
+bool conv_few_in_supported(int Cin, int Cout, int taps, int H, int W);  // ALGO_DIRECT's second kernel (in_conv over the data channels)
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s);
 long conv_bf16x3_packed_floats(int Cin, int Cout);
 int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);

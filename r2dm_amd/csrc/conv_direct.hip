@@ -6,6 +6,7 @@
 // input channels walked in chunks of 8 through an LDS halo tile (wrap in W, zero in H), weights in LDS once per block,
 // every thread accumulates its pixel's Cout outputs over (channel, tap) in fp32.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace r2dm {
 
@@ -169,9 +170,120 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
     }
 }
 
+// ---- few INPUT channels (in_conv over the data channels: 2 -> 64 at full resolution) -----------------------------------
+// 0.3 GFLOP against 134 MB of output per batch of 8: bound by the output stream, while the fp32-MFMA kernel pads 2 input
+// channels to a 16-deep k-step and spends 105 us on it.  Same thread shape as above (4 pixels of one row, wave = 256-column
+// row segment, block = 4 rows): the thread keeps its 3 x 6 input window of every channel in registers and walks the output
+// channels in blocks of 8 with wave-uniform scalar weights; per channel one 16-byte residual load (the constant coordinate
+// map, batch-broadcast, from L2), bias, scale and one 16-byte store.  Fused GroupNorm statistics: four pixels in fp32, fp64
+// beyond, one wave_sum per group, written into the slot grid the MFMA epilogues use (conv_stat_slots: 8 slots per 4 x 64
+// tile and group -- this wave fills the first one of its row's four tiles and zeroes the other seven).
+template <int CI>
+__global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
+    using gcf = const float __attribute__((address_space(1)))*;
+    using gcf4 = const f32x4 __attribute__((address_space(1)))*;
+    using gf4 = f32x4 __attribute__((address_space(1)))*;
+    using gdouble = double __attribute__((address_space(1)))*;
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int nTw = (W + 255) / 256, nTh = H / 4, nTw64 = (W + 63) / 64;  // (H % 4 == 0: launcher)
+    int L = blockIdx.x;
+    const int tw = L % nTw;
+    L /= nTw;
+    const int th = L % nTh;
+    const int b = L / nTh;
+    const int gr = th * 4 + ty, gc0 = tw * 256 + tx * 4;
+    const bool active = gc0 < W;  // (partial last block of a row: the lane takes part in the reductions with zeros)
+    const int gc = active ? gc0 : 0;
+    const int cl = gc == 0 ? W - 1 : gc - 1, cr = gc + 4 >= W ? gc + 4 - W : gc + 4;  // azimuth is periodic
+    float x[CI][3][6];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const gcf pl = (gcf)(p.x.p0 + b * p.x.bs0 + (long)ci * HW);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int r = gr - 1 + k;
+            const bool ok = r >= 0 && r < H;  // rows outside the image are zero padding
+            const int rb = (ok ? r : gr) * W;
+            const f32x4 v = *(gcf4)(pl + rb + gc);
+            const float l = pl[rb + cl], rr = pl[rb + cr];
+            x[ci][k][0] = ok ? l : 0.f;
+            x[ci][k][5] = ok ? rr : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[ci][k][1 + j] = ok ? v[j] : 0.f;
+        }
+    }
+    const float sc = p.scale ? *(gcf)p.scale : 1.0f;
+    const gcf wg = (gcf)p.w;
+    const long pix = (long)gr * W + gc;
+    const int bpg = p.stat ? p.stat_cpg >> 3 : 1;  // 8-channel blocks per group
+    const int S = p.stat_slots >> 1;
+    double gs = 0.0, gq = 0.0;
+    for (int co0 = 0; co0 < p.Cout; co0 += 8) {
+        float acc[8][4];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+            const gcf wk = wg + (long)(co0 + o) * CI * 9;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float w = wk[ci * 9 + t];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(w, x[ci][t / 3][j + t % 3], acc[o][j]);
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float bo = ((gcf)p.bias)[co0 + o];
+            f32x4 v = f32x4{acc[o][0] + bo, acc[o][1] + bo, acc[o][2] + bo, acc[o][3] + bo};
+            if (p.res) v = *(gcf4)(p.res + b * p.res_bs + (long)(co0 + o) * HW + pix) + v;
+            v *= sc;  // (1.0f without p.scale: exact)
+            if (active) {
+                *(gf4)(p.y + b * p.y_bs + (long)(co0 + o) * HW + pix) = v;
+                if (p.stat) {
+                    gs += (double)((v[0] + v[1]) + (v[2] + v[3]));
+                    gq += (double)fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                }
+            }
+        }
+        if (p.stat && ((co0 >> 3) + 1) % bpg == 0) {  // the group's last block: wave totals into the slot grid
+            const double ts = wave_sum_f64(gs), tq = wave_sum_f64(gq);
+            gs = gq = 0.0;
+            const int g = p.stat_goff + co0 / p.stat_cpg;
+            const int j = tx & 3, hf = (tx >> 2) & 1, tile = 4 * tw + j;
+            if (tx < 8 && tile < nTw64) {
+                const int slot = (th * nTw64 + tile) * 4 + ty;
+                gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot + (size_t)S * hf) * 2);
+                o[0] = tx == 0 ? ts : 0.0;
+                o[1] = tx == 0 ? tq : 0.0;
+            }
+        }
+    }
+}
+
+// few inputs: Cin <= 4 data channels into Cout % 8 == 0 channels; single-source input, whole 4-row tiles, 16-byte rows
+bool conv_few_in_supported(int Cin, int Cout, int taps, int H, int W) {
+    return taps == 9 && Cin >= 1 && Cin <= 4 && Cout > dc::MAXCO && Cout % 8 == 0 && H % 4 == 0 && W % 4 == 0;
+}
+
 bool conv_direct_supported(int Cout, int taps) { return taps == 9 && Cout >= 1 && Cout <= dc::MAXCO; }
 
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s) {
+    if (p.Cout > dc::MAXCO) {  // the few-input kernel
+        if (!conv_few_in_supported(p.Cin, p.Cout, p.taps, p.H, p.W) || p.prologue != PRO_NONE || p.x.p1 || p.range) return hipErrorInvalidValue;
+        if (p.stat && (p.stat_cpg % 8 || p.Cout % p.stat_cpg || p.stat_slots != conv_stat_slots(p.H, p.W))) return hipErrorInvalidValue;
+        const unsigned nb = (unsigned)(((p.W + 255) / 256) * (p.H / 4) * p.B);
+        switch (p.Cin) {
+            case 1: conv_few_in_kernel<1><<<nb, 256, 0, s>>>(p); break;
+            case 2: conv_few_in_kernel<2><<<nb, 256, 0, s>>>(p); break;
+            case 3: conv_few_in_kernel<3><<<nb, 256, 0, s>>>(p); break;
+            default: conv_few_in_kernel<4><<<nb, 256, 0, s>>>(p); break;
+        }
+        return hipGetLastError();
+    }
     if (!conv_direct_supported(p.Cout, p.taps) || p.prologue != PRO_NONE || p.res || p.scale || p.stat) return hipErrorInvalidValue;
     if (p.W % 4 == 0) {  // (rows of 16-byte vectors: every U-Net geometry)
         const unsigned nb = (unsigned)(((p.W + 255) / 256) * ((p.H + 4 * DC_ROWS - 1) / (4 * DC_ROWS)) * p.B);

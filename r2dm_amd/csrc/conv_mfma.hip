@@ -502,9 +502,11 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
 hipError_t launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int co_tile, int cin_pad,
                             hipStream_t s, int algo, int src_cin, int src_off) {
     if (src_cin <= 0) src_cin = Cin;
-    if (algo == ALGO_DIRECT)
-        return src_cin == Cin ? hipMemcpyAsync(dst, w, (size_t)Cout * Cin * taps * sizeof(float), hipMemcpyDeviceToDevice, s)
-                              : hipErrorInvalidValue;
+    if (algo == ALGO_DIRECT) {  // OIHW as is (an input-channel slice: row by row)
+        if (src_cin == Cin) return hipMemcpyAsync(dst, w, (size_t)Cout * Cin * taps * sizeof(float), hipMemcpyDeviceToDevice, s);
+        return hipMemcpy2DAsync(dst, (size_t)Cin * taps * sizeof(float), w + (size_t)src_off * taps, (size_t)src_cin * taps * sizeof(float),
+                                (size_t)Cin * taps * sizeof(float), Cout, hipMemcpyDeviceToDevice, s);
+    }
     if (algo == ALGO_BF16X3) return src_cin == Cin ? launch_pack_conv_bf16x3(w, dst, Cout, Cin, co_tile, s) : hipErrorInvalidValue;
     if (algo == ALGO_F16X2) return hipErrorInvalidValue;  // (launch_pack_conv_f16x2: needs the range flag)
     const int nT = (Cout + co_tile - 1) / co_tile;

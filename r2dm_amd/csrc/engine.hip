@@ -131,14 +131,20 @@ struct r2dm_handle {
     }
     void raw_at(const std::string& key, int64_t numel, size_t off) { slots.push_back({key, numel, SLOT_RAW, off, {}}); }
     // the weight-only half of a convolution whose source tensor is shared with another layer (no bias slot)
-    ConvLayer conv_slice(const std::string& wkey, int src_cin, int src_off, int cin, int cout, int ksize, long px_batch) {
+    // few_in: the slice runs at (H, W) with few input channels -- the direct kernel if the shape fits (conv_direct.hip)
+    ConvLayer conv_slice(const std::string& wkey, int src_cin, int src_off, int cin, int cout, int ksize, long px_batch,
+                         int H = 0, int W = 0) {
         ConvLayer L;
         L.cin = cin;
         L.cout = cout;
         L.taps = ksize * ksize;
-        L.algo = ALGO_F32;
+        static const bool force_f32 = [] {
+            const char* e = getenv("R2DM_CONV_ALGO");
+            return e && e[0] == 'f';
+        }();
+        L.algo = (!force_f32 && H > 0 && conv_few_in_supported(cin, cout, L.taps, H, W)) ? ALGO_DIRECT : ALGO_F32;
         L.co_tile = conv_pick_co_tile(cout, L.taps, px_batch);
-        L.cin_pad = conv_cin_pad(cin, L.taps, L.co_tile);
+        L.cin_pad = L.algo == ALGO_DIRECT ? cin : conv_cin_pad(cin, L.taps, L.co_tile);
         L.src_cin = src_cin;
         L.src_off = src_off;
         L.w = take(L.packed_elems());
@@ -188,7 +194,7 @@ void build_plan(r2dm_handle* h) {
     h->b2 = h->raw("time_embedding.3.bias", T);
     if (c.coord_channels > 0) {
         const int cin = c.in_channels + c.coord_channels;
-        h->in_conv = h->conv_slice("in_conv.weight", cin, 0, c.in_channels, C0, 3, px1);
+        h->in_conv = h->conv_slice("in_conv.weight", cin, 0, c.in_channels, C0, 3, px1, c.height, c.width);
         h->in_conv_c = h->conv_slice("in_conv.weight", cin, c.in_channels, c.coord_channels, C0, 3, (long)c.height * c.width);
         h->in_conv_c.b = h->raw("in_conv.bias", C0);
         h->zero_bias = h->take(C0);
@@ -389,7 +395,9 @@ struct Ctx {
     }
     // which convolution kernels write fused statistics: the split-bf16 kernels and the fp32-MFMA kernel with >= 64-channel
     // tiles; the 32-channel fp32 tile (Cout <= 32) and the direct kernel do not
-    static bool emits_stats(const ConvLayer& L) { return L.algo == ALGO_BF16X3 || (L.algo == ALGO_F32 && L.co_tile >= 64); }  // (and ALGO_F16X2, a second packing of a BF16X3 layer)
+    static bool emits_stats(const ConvLayer& L) {
+        return L.algo == ALGO_BF16X3 || (L.algo == ALGO_F32 && L.co_tile >= 64) || (L.algo == ALGO_DIRECT && L.cout > 4);
+    }  // (and ALGO_F16X2, a second packing of a BF16X3 layer)
     float2* finalize(const Sink& k, int H, int W, const float* gamma, const float* beta, const float* ada) {
         float2* aff = (float2*)ar->alloc((size_t)B * k.C * sizeof(float2));
         if (!dry()) {

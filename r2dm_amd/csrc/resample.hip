@@ -8,6 +8,7 @@
 // W pass first, then H, like the reference's two depthwise convolutions (ops.py:131-132).
 // The FIR window is fixed: the host side refuses checkpoints whose `kernel` buffers differ.
 #include "common.h"
+#include <stdlib.h>
 #include "wave_ops.h"
 
 namespace r2dm {
@@ -44,6 +45,54 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict_
         }
         float2* out = reinterpret_cast<float2*>(y + b * ybs + (long)c * Ho * Wo + (long)i * Wo + 2 * t);
         *out = make_float2(o0, o1);
+    }
+}
+
+// one thread -> a 2 x 4 output patch (rows 2i, 2i+1 of the block's pair, columns 4t .. 4t+3): input columns 8t-1 .. 8t+8 of
+// 6 rows = 24 load instructions for 8 outputs.  (One output pair per thread was 12 loads for 2 outputs and bound by the CU's
+// address pipeline, not by HBM: 3.7 TB/s.)  Needs W % 8 == 0, H % 4 == 0; the generic kernel below takes the rest.
+__global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
+                                                             long ybs, int C, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1, Wq = Wo >> 2, Hq = Ho >> 1;  // Wq threads per pair of output rows
+    const long per_plane = (long)Hq * Wq;
+    const long total = per_plane * C;
+    const int b = blockIdx.y;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx / per_plane;
+        const long rem = idx % per_plane;
+        const int i2 = rem / Wq, t = rem % Wq;
+        const float* xp = x + b * xbs + (long)c * H * W;
+        const int cl = 8 * t - 1 < 0 ? W - 1 : 8 * t - 1;
+        const int cr = 8 * t + 8 >= W ? 0 : 8 * t + 8;
+        float h[6][4];  // horizontally filtered rows 4 i2 - 1 .. 4 i2 + 4 at the four output columns
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const int r = 4 * i2 + a - 1;
+            if (r >= 0 && r < H) {
+                const float* row = xp + (long)r * W;
+                const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + 8 * t), m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
+                const float l = row[cl], rr = row[cr];
+                h[a][0] = 0.125f * l + 0.375f * m0[0] + 0.375f * m0[1] + 0.125f * m0[2];
+                h[a][1] = 0.125f * m0[1] + 0.375f * m0[2] + 0.375f * m0[3] + 0.125f * m1[0];
+                h[a][2] = 0.125f * m0[3] + 0.375f * m1[0] + 0.375f * m1[1] + 0.125f * m1[2];
+                h[a][3] = 0.125f * m1[1] + 0.375f * m1[2] + 0.375f * m1[3] + 0.125f * rr;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[a][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {  // output row 2 i2 + o takes input rows (2 o) .. (2 o + 3) of the six; same order of
+            f32x4 v;                    // additions as the generic kernel: bit-identical results
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc += ((a == 0 || a == 3) ? 0.125f : 0.375f) * h[2 * o + a][j];
+                v[j] = acc;
+            }
+            *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v;
+        }
     }
 }
 
@@ -110,6 +159,11 @@ static int grid_for(long total) {
 
 hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s) {
     if ((W & 3) || (H & 1)) return hipErrorInvalidValue;
+    if (W % 8 == 0 && H % 4 == 0 && getenv("R2DM_FIR_NARROW") == nullptr) {
+        const long tot = (long)C * (H / 4) * (W / 8);
+        fir_down2_wide_kernel<<<dim3(grid_for(tot), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
+        return hipGetLastError();
+    }
     const long total = (long)C * (H / 2) * (W / 4);
     fir_down2_kernel<<<dim3(grid_for(total), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
     return hipGetLastError();

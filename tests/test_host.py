@@ -114,6 +114,19 @@ def test_coefficient_tables_match_reference_schedule(golden):
         # and it does not depend on how many rows are evaluated together
         c1, k1, _ = d._coefficients(t[3:4], t[4:5], "ddpm", 0.0)
         assert torch.equal(c1, cond[3:4]) and torch.equal(k1, coef[3:4])
+    # sample() keeps its last tables (same schedule + step count + batch + mode -> the same device tensors, nothing rebuilt);
+    # anything that enters the table is part of the key
+    c8, k8, m8 = d._sample_tables(8, 2, "ddpm", 0.0, "cpu")
+    t8 = torch.linspace(1.0, 0.0, 9)
+    r8 = d._coefficients(t8[:-1], t8[1:], "ddpm", 0.0)
+    assert torch.equal(c8, r8[0][:, None].expand(8, 2)) and torch.equal(k8, r8[1][:, None, :].expand(8, 2, 8)) and m8 == r8[2]
+    assert d._sample_tables(8, 2, "ddpm", 0.0, "cpu")[1] is k8
+    assert d._sample_tables(8, 3, "ddpm", 0.0, "cpu")[1].shape == (8, 3, 8)
+    assert not torch.equal(d._sample_tables(8, 2, "ddim", 0.0, "cpu")[1], k8)
+    assert d._sample_tables(32, 2, "ddpm", 0.0, "cpu")[1].shape == (32, 2, 8)
+    for S in range(40, 52):  # (bounded: old entries leave)
+        d._sample_tables(S, 1, "ddpm", 0.0, "cpu")
+    assert len(d.__dict__["_tables"]) <= 8
     with pytest.raises(ValueError, match="invalid mode"):
         d._coefficients(t[:-1], t[1:], "euler", 0.0)
     with pytest.raises(ValueError):

@@ -55,7 +55,8 @@ enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2 };
 // products per fp32 product, two fp32 accumulators (conv_f16x2.hip): more accurate than either of the above on the
 // matrix pipe (profiles/r02_f16x2_probe.txt) at half the products of ALGO_BF16X3, but operands must fit the fp16 range
 // -- the engine uses it for GroupNorm-normalised inputs only, behind a range flag.
-enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1, ALGO_DIRECT = 2, ALGO_F16X2 = 3 };
+// ALGO_P1F16: the 1x1 convolutions around the attention core in the ALGO_F16X2 arithmetic (proj_f16x2.hip)
+enum ConvAlgo { ALGO_F32 = 0, ALGO_BF16X3 = 1, ALGO_DIRECT = 2, ALGO_F16X2 = 3, ALGO_P1F16 = 4 };
 
 struct ConvParams {
     Src x;               // input activation
@@ -105,6 +106,10 @@ long conv_f16x2_packed_floats(int Cin, int Cout);
 // range_flag (device int, may be nullptr): bit 0 is set if a weight does not fit the fp16 range
 hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s);
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s);
+bool proj_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
+long proj_f16x2_packed_floats(int Cin, int Cout);
+hipError_t launch_pack_proj_f16x2(const float* w_oi, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s);
+hipError_t launch_proj_f16x2(const ConvParams& p, hipStream_t s);
 
 struct GNParams {
     Src x;

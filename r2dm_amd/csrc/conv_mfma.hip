@@ -539,6 +539,7 @@ int conv_pick_algo(int Cin, int Cout, int taps) {
 long conv_packed_floats(int algo, int Cin, int Cout, int taps, int co_tile, int cin_pad) {
     if (algo == ALGO_BF16X3) return conv_bf16x3_packed_floats(Cin, Cout);
     if (algo == ALGO_F16X2) return conv_f16x2_packed_floats(Cin, Cout);
+    if (algo == ALGO_P1F16) return proj_f16x2_packed_floats(Cin, Cout);
     if (algo == ALGO_DIRECT) return (long)Cout * Cin * taps;  // OIHW as is
     return (long)((Cout + co_tile - 1) / co_tile) * cin_pad * taps * co_tile;
 }
@@ -592,6 +593,7 @@ hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.algo == ALGO_BF16X3) return launch_conv_bf16x3(p, s);
     if (p.algo == ALGO_F16X2) return launch_conv_f16x2(p, s);
     if (p.algo == ALGO_DIRECT) return launch_conv_direct(p, s);
+    if (p.algo == ALGO_P1F16) return launch_proj_f16x2(p, s);
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
     if (p.CinPad != conv_cin_pad(p.Cin, p.taps, p.co_tile)) return hipErrorInvalidValue;
     if (p.H * (long)p.W * 16 >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit element offsets within a chunk

@@ -51,6 +51,9 @@ struct ConvLayer {
     // input is GroupNorm-normalised; selected per launch by the handle's precision mode (r2dm_set_conv_pieces)
     bool f2 = false;
     size_t w_f2 = 0;
+    // ... and for ALGO_P1F16 (proj_f16x2.hip): the 1x1 projections of the attention block
+    bool p1 = false;
+    size_t w_p1 = 0;
     size_t packed_elems() const { return (size_t)conv_packed_floats(algo, cin, cout, taps, co_tile, cin_pad); }
 };
 
@@ -170,6 +173,10 @@ struct r2dm_handle {
             L.f2 = true;
             L.w_f2 = take((size_t)conv_f16x2_packed_floats(cin, cout));
         }
+        if (L.algo == ALGO_F32 && H > 0 && proj_f16x2_supported(cin, cout, L.taps, H, W)) {
+            L.p1 = true;
+            L.w_p1 = take((size_t)proj_f16x2_packed_floats(cin, cout));
+        }
         slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
         L.b = raw(bkey, cout);
         return L;
@@ -260,8 +267,8 @@ void build_plan(r2dm_handle* h) {
             st.at.scale = h->raw(q + "scale", 1);
             st.at.gamma = h->raw(q + "norm.weight", d.cout);
             st.at.beta = h->raw(q + "norm.bias", d.cout);
-            st.at.qkv = h->conv(q + "attn.in_proj_weight", q + "attn.in_proj_bias", d.cout, 3 * d.cout, 1, px);
-            st.at.proj = h->conv(q + "attn.out_proj.weight", q + "attn.out_proj.bias", d.cout, d.cout, 1, px);
+            st.at.qkv = h->conv(q + "attn.in_proj_weight", q + "attn.in_proj_bias", d.cout, 3 * d.cout, 1, px, c.height >> d.level, c.width >> d.level);
+            st.at.proj = h->conv(q + "attn.out_proj.weight", q + "attn.out_proj.bias", d.cout, d.cout, 1, px, c.height >> d.level, c.width >> d.level);
         }
         if (d.up)  // upsample then conv at the finer resolution (efficient_unet.py:169-173)
             st.uconv = h->conv(p + "upsample.1.weight", p + "upsample.1.bias", d.cout, d.cout, 3, px << 2, c.height >> (d.level - 1), c.width >> (d.level - 1));
@@ -467,6 +474,11 @@ struct Ctx {
                 p.w = blob(L.w_f2);
                 p.co_tile = 64;
             }
+            if (L.p1 && h->conv_pieces == 2 && pro != PRO_AFFINE_SILU && (pro != PRO_NONE || input_bounded)) {
+                p.algo = ALGO_P1F16;
+                p.w = blob(L.w_p1);
+                p.co_tile = 64;
+            }
             if (track_out && h->conv_pieces == 2 && p.algo != ALGO_DIRECT) p.range = (int*)blob(h->range_flag);
             if (fused_stats) {
                 p.stat = sink->p;
@@ -544,7 +556,8 @@ struct Ctx {
         Tensor o = make(a.C, x.H, x.W);
         if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st, f2), "attention");
         drop(qkv);
-        Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff);
+        // (the core's output is a convex combination of v: |o| <= max|qkv|, which the qkv epilogue has recorded)
+        Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff, false, f2);
         drop(o);
         return y;
     }
@@ -806,6 +819,8 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
                                  s.conv.cin_pad, st, s.conv.algo, s.conv.src_cin, s.conv.src_off));
         if (s.conv.f2)
             HIP_TRY(launch_pack_conv_f16x2(src, h->blob + s.conv.w_f2, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st));
+        if (s.conv.p1)
+            HIP_TRY(launch_pack_proj_f16x2(src, h->blob + s.conv.w_p1, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st));
     }
     h->cmap_ready = false;  // (any reload: cheap to recompute)
     return 0;
@@ -931,6 +946,7 @@ int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t
     const int ct = algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, taps, (long)B * H * W);
     int64_t n = (int64_t)conv_packed_floats(algo, cin, cout, taps, ct, algo != ALGO_F32 ? cin : conv_cin_pad(cin, taps, ct));
     if (algo == ALGO_BF16X3 && conv_f16x2_supported(cin, cout, taps, H, W)) n = std::max<int64_t>(n, conv_f16x2_packed_floats(cin, cout) + 64);
+    if (proj_f16x2_supported(cin, cout, taps, H, W)) n = std::max<int64_t>(n, proj_f16x2_packed_floats(cin, cout) + 64);
     return n;
 }
 
@@ -947,12 +963,17 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale)) p.algo = ALGO_F32;  // plain convolutions only
     // per-op tests: with pieces = 2 every shape the f16x2 kernel covers goes there (the engine restricts it to normalised inputs)
     if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces == 2 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
-    p.co_tile = p.algo == ALGO_F16X2 ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    if (p.algo == ALGO_F32 && g_single_kernel_pieces == 2 && prologue != PRO_AFFINE_SILU && proj_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_P1F16;
+    p.co_tile = (p.algo == ALGO_F16X2 || p.algo == ALGO_P1F16) ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
     p.CinPad = p.algo != ALGO_F32 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
     if (p.algo == ALGO_F16X2) {  // the range flag: the last int of the scratch (r2dm_conv_packed_elems reserves it)
         int* flag = (int*)(w_packed + conv_f16x2_packed_floats(cin, cout));
         HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
         HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, flag, st));
+    } else if (p.algo == ALGO_P1F16) {
+        int* flag = (int*)(w_packed + proj_f16x2_packed_floats(cin, cout));
+        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+        HIP_TRY(launch_pack_proj_f16x2(w, w_packed, cout, cin, flag, st));
     } else {
         HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
     }

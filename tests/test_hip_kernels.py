@@ -125,6 +125,37 @@ def test_conv1x1(O, H, cin, cout, h, w):
     assert max_abs(y, O.conv_ring(x.double(), wt.double(), b.double())) < 1e-5
 
 
+@pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
+@pytest.mark.parametrize("pro", [0, 1])
+@pytest.mark.parametrize("cin,cout,h,w", [(256, 768, 8, 128), (512, 512, 8, 128), (64, 64, 16, 256)])
+def test_conv1x1_fp16_pipe_and_fp32_mfma(O, H, cin, cout, h, w, pro):
+    """The attention block's projections: split fp16 operands on the fp16 matrix pipe (proj_f16x2.hip, pieces = 2) and the
+    fp32-input MFMA (conv_mfma.hip, pieces = 3) against an fp64 product, plain and GroupNorm-affine input, with residual
+    and scale.  Both fp32-class; the split-operand form is the more accurate one (one truncating accumulator update per 16
+    k-values instead of eight)."""
+    B = 3
+    x, wt, b = rnd(1, B, cin, h, w), rnd(2, cout, cin, 1, 1) / math.sqrt(cin), rnd(3, cout)
+    res = rnd(4, B, cout, h, w)
+    aff = torch.stack([torch.rand(B, cin) + 0.5, torch.randn(B, cin) * 0.3], -1).contiguous() if pro else None
+    xa = x.double()
+    if pro:
+        xa = xa * aff[..., 0].double()[:, :, None, None] + aff[..., 1].double()[:, :, None, None]
+    ref = (res.double() + O.conv_ring(xa, wt.double(), b.double())) * 0.70710678
+    out = {}
+    for pieces in (2, 3):
+        H.set_conv_pieces(pieces)
+        try:
+            out[pieces] = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), aff=None if aff is None else aff.to(DEV), prologue=pro,
+                                        residual=res.to(DEV), scale=0.70710678).cpu()
+        finally:
+            H.set_conv_pieces(2)
+    e = {k: (max_abs(v, ref), (v.double() - ref).pow(2).mean().sqrt().item()) for k, v in out.items()}
+    print(f"conv1x1 {cin}->{cout} pro={pro}: f16x2 max {e[2][0]:.2e} rms {e[2][1]:.2e} | f32 mfma max {e[3][0]:.2e} rms {e[3][1]:.2e}")
+    assert not torch.equal(out[2], out[3])  # the mode switch took effect
+    assert e[2][0] < 1e-5 and e[3][0] < 1e-5
+    assert e[2][1] < 1.2 * e[3][1]
+
+
 def test_conv_golden(golden, H, sd):
     g = golden("ops")
     p, q = "d_block1.residual_blocks.1.", "u_block3.residual_blocks.0."

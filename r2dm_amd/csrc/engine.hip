@@ -78,6 +78,10 @@ struct Stage {
     ConvLayer dconv, uconv;
     bool out_tracked = false;  // the stage's last convolution records max|output| in the range flag (its consumer is the next
                                // stage's down-sampling convolution on the f16x2 path)
+    // the 1x1 skip convolution of an up stage's first block reads the raw concatenation [previous up stage | down-path skip
+    // tensor]: it runs on the fp16 matrix pipe (proj_f16x2.hip) if BOTH tensors' producers record max|output|
+    bool track_final = false;     // whichever convolution produces the stage's output records max|output|
+    bool skip_in_bounded = false;  // ... which every producer of this stage's input does
     std::vector<ResLayer> res;
     AttnLayer at;
 };
@@ -258,7 +262,7 @@ void build_plan(r2dm_handle* h) {
             row += 2 * r.cout;
             r.conv2 = h->conv(q + "conv2.weight", q + "conv2.bias", r.cout, r.cout, 3, px, c.height >> d.level, c.width >> d.level);
             r.has_skip = r.cin != r.cout;
-            if (r.has_skip) r.skip = h->conv(q + "skip.weight", q + "skip.bias", r.cin, r.cout, 1, px);
+            if (r.has_skip) r.skip = h->conv(q + "skip.weight", q + "skip.bias", r.cin, r.cout, 1, px, c.height >> d.level, c.width >> d.level);
             st.res.push_back(r);
         }
         if (d.attn) {
@@ -281,6 +285,14 @@ void build_plan(r2dm_handle* h) {
         Stage& a = h->stages[s];
         const Stage& b = h->stages[s + 1];
         a.out_tracked = b.down && b.dconv.f2 && !a.attn && !a.up && !a.res.empty() && a.res.back().conv2.f2;
+    }
+    // up stages: input of stage 4 = output of stage 3; of stage 4 + k (k = 1..3) = [output of stage 3 + k | output of stage 3 - k]
+    for (int s = 4; s < 8; ++s) {
+        Stage& a = h->stages[s];
+        if (a.res.empty() || !a.res[0].has_skip || !a.res[0].skip.p1) continue;
+        a.skip_in_bounded = true;
+        h->stages[s - 1].track_final = true;
+        if (s > 4) h->stages[7 - s].track_final = true;
     }
 }
 
@@ -518,7 +530,7 @@ struct Ctx {
     // efficient_unet.py:95-110.  `in_stats`: fused statistics of x (if its producer left them);
     // `out` / `out_goff`: where the statistics of this block's output go (the next GroupNorm's sink).
     Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,
-                          bool track_out = false) {
+                          bool track_out = false, bool skip_bounded = false) {
         float2* a1 = norm(in_stats, x, H, W, blob(r.g1), blob(r.b1), nullptr);
         Sink s1 = make_sink(r.cout, H, W);
         Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, a1, nullptr, 0, false, nullptr, &s1, 0);
@@ -529,7 +541,7 @@ struct Ctx {
         const Tensor* res;
         Tensor ident;
         if (r.has_skip) {
-            skip = conv(r.skip, x, H, W, PRO_NONE, nullptr, nullptr, 0, false);
+            skip = conv(r.skip, x, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, skip_bounded);
             res = &skip;
         } else {
             ident.p = const_cast<float*>(x.p0);  // identity skip: block input is single-source here
@@ -546,7 +558,7 @@ struct Ctx {
     }
 
     // efficient_unet.py:42-53
-    Tensor attention_block(const AttnLayer& a, const Tensor& x, const Sink& in_stats, const Sink* out, int out_goff) {
+    Tensor attention_block(const AttnLayer& a, const Tensor& x, const Sink& in_stats, const Sink* out, int out_goff, bool track_out = false) {
         float2* aff = norm(in_stats, src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
         // precision mode 2: the attention core runs on the fp16 matrix pipe (attention.hip) and needs |q|, |k|, |v| < 65504: the
         // projection's epilogue records max|qkv| in the range flag
@@ -557,7 +569,7 @@ struct Ctx {
         if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st, f2), "attention");
         drop(qkv);
         // (the core's output is a convex combination of v: |o| <= max|qkv|, which the qkv epilogue has recorded)
-        Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff, false, f2);
+        Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff, false, f2, track_out);
         drop(o);
         return y;
     }
@@ -593,7 +605,8 @@ struct Ctx {
                 dst = out;
                 goff = out_goff;
             }
-            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, last && s.out_tracked && h->conv_pieces == 2);
+            const bool tf = h->conv_pieces == 2 && last && ((s.out_tracked) || (s.track_final && !s.attn && !s.up));
+            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, tf, i == 0 && s.skip_in_bounded && h->conv_pieces == 2);
             if (carry_owned) drop_sink(carry);
             if (have) drop(cur);
             cur = nxt;
@@ -602,7 +615,7 @@ struct Ctx {
             carry_owned = next.p != nullptr;
         }
         if (s.attn) {
-            Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff);
+            Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff, s.track_final && !s.up && h->conv_pieces == 2);
             if (carry_owned) drop_sink(carry);
             carry_owned = false;
             drop(cur);
@@ -614,7 +627,7 @@ struct Ctx {
             const bool track = s.uconv.f2 && h->conv_pieces == 2;  // the f16x2 convolution below needs max|u| < 65504
             if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? (int*)blob(h->range_flag) : nullptr), "fir_up2");
             drop(cur);
-            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track);
+            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track, s.track_final && h->conv_pieces == 2);
             drop(u);
         }
         return cur;

@@ -260,6 +260,27 @@ def test_f16x2_range_bound_fails_loudly():
 
 
 @pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
+def test_f16x2_skip_convolution_input_range_fails_loudly():
+    """The 1x1 skip convolution of an up block reads the raw concatenation [previous up stage | skip tensor] on the fp16
+    matrix pipe (proj_f16x2.hip): both producers record max|output|.  An up-sampling convolution whose bias pushes its output
+    out of the fp16 range (the GroupNorm behind it would normalise that away) must make the forward fail; the bf16x3 mode
+    runs the same weights."""
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    ck = dict(synthetic_ckpt())
+    ck["ema_weights"] = dict(ck["ema_weights"])
+    key = next(k for k in ck["ema_weights"] if k.endswith("u_block4.upsample.1.bias"))
+    ck["ema_weights"][key] = torch.full_like(ck["ema_weights"][key], 1.0e5)
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    x, c = rnd(97, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
+    with pytest.raises(R2DMError, match="fp16 range"):
+        ddpm.model(x, c)
+    ddpm.model.set_precision("fp32-bf16x3")
+    assert torch.isfinite(ddpm.model(x, c)).all()
+
+
+@pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
 def test_f16x2_tracked_activation_range_fails_loudly():
     """The down- and up-sampling convolutions have no GroupNorm in front: on the f16x2 path their inputs' running maximum is
     recorded by the producing kernel (conv epilogue / fir_up2).  An input scaled so that the residual stream leaves the

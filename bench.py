@@ -281,7 +281,7 @@ def main():
                                      "2^11-scaled fp16 residual), 3 products per fp32 product, two fp32 accumulators; fused GN+SiLU "
                                      "prologue, residual / GroupNorm-statistics epilogue; warp-specialised, persistent",
                 "conv_bf16x3_*": "same contract on the bf16 matrix pipe: three bf16 pieces, 6 products per fp32 product",
-                "conv_mfma_kernel + conv_direct_kernel": "fp32-input MFMA (1x1, in_conv) and the direct out_conv kernel"}
+                "1x1 / in / out convolutions": "proj_f16x2_kernel (1x1 skips and attention projections: split fp16 operands; fp32-input MFMA with precision fp32-bf16x3), conv_few_in_kernel (in_conv), conv_direct_rows_kernel (out_conv)"}
         conv = []
         for name, ms, fl, n in classes:
             if n == 0:
@@ -295,7 +295,7 @@ def main():
                 e["frac"] = e["tflops"] / e["peak_tflops"]
                 e["matrix_pipe_tflops"] = e["tflops"] * NPROD[name]  # what the MFMA units actually execute
             else:
-                e["peak_tflops"] = PEAK_FP32 / 1e12
+                e["peak_tflops"] = PEAK_FP32 / 1e12  # (a mixed class: HBM-bound direct kernels + fp16-pipe projections; the fp32 peak is a yardstick only)
                 e["frac"] = e["tflops"] / e["peak_tflops"]
             conv.append(e)
         conv.sort(key=lambda e: -e["ms_per_step"])

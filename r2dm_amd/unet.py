@@ -305,7 +305,7 @@ class EfficientUNet(nn.Module):
         _lib.check(_lib.lib().r2dm_profile_read(self._engine.h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
         return ms.value, fl.value, n.value
 
-    CONV_CLASSES = ("conv_f16x2_kernel", "conv_bf16x3_*", "conv_mfma_kernel + conv_direct_kernel")
+    CONV_CLASSES = ("conv_f16x2_kernel", "conv_bf16x3_*", "1x1 / in / out convolutions")
 
     def read_conv_profile_classes(self):
         """-> [(kernel class, milliseconds, algorithmic flops, launches)] since profile_convs(True); resets."""

@@ -19,7 +19,7 @@ out.append(f"\nall kernels: {tot / 1e6:.2f} ms over {nsteps} steps = {tot / 1e6 
 def cls(name):
     if 'conv_f16x2_kernel' in name: return 'conv_f16x2_kernel'
     if 'conv_bf16x3' in name and 'pack' not in name: return 'conv_bf16x3_*'
-    if ('conv_mfma' in name or 'conv_direct' in name or 'conv_few_in' in name or 'proj_f16x2' in name) and 'pack' not in name: return 'conv_mfma_kernel + conv_direct_kernel'
+    if ('conv_mfma' in name or 'conv_direct' in name or 'conv_few_in' in name or 'proj_f16x2' in name) and 'pack' not in name: return '1x1 / in / out convolutions'
     return None
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:

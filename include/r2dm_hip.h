@@ -77,16 +77,17 @@ size_t r2dm_workspace_bytes(const r2dm_handle* h, int32_t batch);
 int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t batch,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* -- operand split of the 3x3 convolutions on the matrix pipe (all of them compute fp32 products to fp32 accuracy or
+/* -- operand split of the convolutions on the matrix pipe (all of them compute fp32 products to fp32 accuracy or
  *    better; there is no reduced-precision mode -- the reference's fp16 autocast bulk mode, sample_and_save.py:70,
  *    utils/option.py:49, has no counterpart here because the parity path is already the fast one):
- *      pieces = 2 (default): fp16 piece + 2^11-scaled fp16 residual (exact to 22 bits), 3 products, two accumulators
- *                 (conv_f16x2.hip) for the convolutions whose input is GroupNorm-normalised -- the residual blocks' --
- *                 and three bf16 pieces / 6 products (conv_bf16x3.hip) for the rest (down / up-sampling convolutions,
- *                 whose raw inputs have no a-priori bound);
- *      pieces = 3: three bf16 pieces everywhere (fp32 operand range; the round-1 parity mode).
- *    fp16 tops out at 65504: with pieces = 2 the GroupNorm kernels bound every normalised tensor (|gamma'| sqrt(n) +
- *    |beta'|, Samuelson) and weight packing checks the weights; r2dm_check_range reports a violation.
+ *      pieces = 2 (default): fp16 piece + 2^11-scaled fp16 residual (exact to 22 bits), 3 products, two accumulators:
+ *                 conv_f16x2.hip for every 3x3 convolution, proj_f16x2.hip for every 1x1 convolution, the attention
+ *                 core likewise.  An operand is either GroupNorm-normalised (bounded by |gamma'| sqrt(n) + |beta'|,
+ *                 Samuelson, evaluated by the GroupNorm kernels) or its producer records max|output| (conv epilogues,
+ *                 fir_up2); weight packing checks the weights;
+ *      pieces = 3: three bf16 pieces / 6 products (conv_bf16x3.hip) for the 3x3 convolutions, the fp32-input MFMA for
+ *                 the 1x1 convolutions and the attention core (fp32 operand range; the round-1 parity mode).
+ *    fp16 tops out at 65504: with pieces = 2 r2dm_check_range reports a violation of any of these bounds.
  *    h == NULL sets the mode of the single-kernel entry r2dm_conv2d_ring. */
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
 

@@ -314,10 +314,12 @@ def main():
             "config": {"workload": cf["workload"] + f"; timed = one sample() call of --steps reverse steps, value scaled to {S} steps",
                        "baseline_config": args.config, "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
                        "sampler": cf["mode"], "sampler_steps": S, "operand_split": args.precision, "clock_prewarm_s": args.prewarm_s,
-                       "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply on the matrix pipe "
-                                     "with every fp32 operand split exactly -- fp16 + scaled fp16 residual (22 bits, 3 products, "
-                                     "residual blocks) or three bf16 pieces (24 bits, 6 products, the other 3x3 convolutions" +
-                                     ("" if args.precision == "fp32" else "; here: everywhere") + "); both measured fp32-class "
+                       "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the convolutions and the attention core multiply on "
+                                     "the matrix pipe with every fp32 operand split exactly -- " +
+                                     ("fp16 + scaled fp16 residual (22 bits, 3 products, two accumulators) for all 3x3 and 1x1 convolutions "
+                                      "and the attention core" if args.precision == "fp32" else
+                                      "three bf16 pieces (24 bits, 6 products) for the 3x3 convolutions, fp32-input MFMA for the 1x1 "
+                                      "convolutions and the attention core") + "; both measured fp32-class "
                                      "(tests/test_hip_kernels.py::test_conv3x3_both_operand_splits)",
                        "parallelism": f"dp{world} (independent seeds, no step-loop collective)"},
         }

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 //                                                    s*16 + (j/4)*8 + half*4 + j%4 (the key register r = 8s + j of that half holds)
 // Range: q, k, v must fit fp16 (|v| < 65504): the engine has the producing qkv convolution record max|qkv| in the range flag
 // (r2dm_check_range); with r2dm_set_conv_pieces(h, 3) the fp32-MFMA kernel above runs instead.
-template <int D>
+// NPLK = 1: the h planes alone -- one fp16 product per MAC (Q, K, V and P rounded to fp16, fp32 accumulation and softmax): the
+// reduced-precision bulk mode (conv_f16x2.hip).
+template <int D, int NPLK>
 __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N,
                                                               float scale) {
     constexpr int KROW = D * 2 + 16, VROW = 32 * 2 + 16;          // bytes per LDS row (16 bytes of padding: conflict-free b128 reads)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
             for (int j = 0; j < 4; ++j) split_f16x2(kreg[2 * j], kreg[2 * j + 1], ph[j], pl[j]);
             unsigned char* dst = Kt + buf * KBUF + k_key * KROW + k_db * 16;
             *reinterpret_cast<u32x4*>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-            *reinterpret_cast<u32x4*>(dst + KPL) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+            if (NPLK == 2) *reinterpret_cast<u32x4*>(dst + KPL) = u32x4{pl[0], pl[1], pl[2], pl[3]};
         }
         if (v_on) {
             // keys v_kq*8 + t: t = 0..3 -> half 0, t = 4..7 -> half 1; position = 16 s + 8 half + 4 (v_kq & 1) + t % 4, s = v_kq >> 1
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
                 split_f16x2(vreg[hh][2], vreg[hh][3], ph1, pl1);
                 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
                 *reinterpret_cast<u32x2*>(dst + hh * 16) = u32x2{ph0, ph1};
-                *reinterpret_cast<u32x2*>(dst + hh * 16 + VPL) = u32x2{pl0, pl1};
+                if (NPLK == 2) *reinterpret_cast<u32x2*>(dst + hh * 16 + VPL) = u32x2{pl0, pl1};
             }
         }
     };
@@ -234,16 +236,18 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
 #pragma unroll
             for (int st = 0; st < KS; ++st) {
                 const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32));
-                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32 + KPL));
                 const f16x8 qhh = __builtin_bit_cast(f16x8, qh[st]), qll = __builtin_bit_cast(f16x8, ql[st]);
-                sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qhh, sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qll, sl, 0, 0, 0);
+                if (NPLK == 2) {
+                    const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32 + KPL));
+                    sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qhh, sl, 0, 0, 0);
+                    sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qll, sl, 0, 0, 0);
+                }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qhh, s, 0, 0, 0);
             }
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = fmaf(sl[r], f2::LINV, s[r]);
+                if (NPLK == 2) s[r] = fmaf(sl[r], f2::LINV, s[r]);
                 mx = fmaxf(mx, s[r]);
             }
             mx = fmaxf(mx, wave_xor32(mx));
@@ -276,9 +280,11 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
 #pragma unroll
                 for (int t = 0; t < TB; ++t) {
                     const f16x8 vh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(vb + t * 32 * VROW + st * 32));
-                    const f16x8 vl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(vb + t * 32 * VROW + st * 32 + VPL));
-                    ol[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, phh, ol[t], 0, 0, 0);
-                    ol[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pll, ol[t], 0, 0, 0);
+                    if (NPLK == 2) {
+                        const f16x8 vl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(vb + t * 32 * VROW + st * 32 + VPL));
+                        ol[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, phh, ol[t], 0, 0, 0);
+                        ol[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pll, ol[t], 0, 0, 0);
+                    }
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, phh, o[t], 0, 0, 0);
                 }
             }
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int e = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            op[(long)e * N] = fmaf(ol[t][r], f2::LINV, o[t][r]) * inv;
+            op[(long)e * N] = (NPLK == 2 ? fmaf(ol[t][r], f2::LINV, o[t][r]) : o[t][r]) * inv;
         }
 }
 
@@ -304,15 +310,19 @@ bool attention_supported(int C, int heads, int N) {
     return (d == 32 || d == 64) && N % 32 == 0 && N > 0;
 }
 
-// f16x2: the fp16-matrix-pipe kernel (q, k, v must fit the fp16 range: the caller guards it); else the fp32-MFMA kernel
-hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, bool f16x2) {
+// planes: 0 = the fp32-MFMA kernel; 2 = the fp16-matrix-pipe kernel with split operands (q, k, v must fit the fp16 range: the
+// caller guards it); 1 = the same kernel with one fp16 product per MAC (reduced-precision bulk mode)
+hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, int planes) {
     if (!attention_supported(C, heads, N)) return hipErrorInvalidValue;
     const int d = C / heads;
     const dim3 g((N / 32 + 3) / 4, heads, B);
     const float scale = 1.0f / sqrtf((float)d);
-    if (f16x2) {
-        if (d == 64) attention_f16x2_kernel<64><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
-        else attention_f16x2_kernel<32><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+    if (planes == 2) {
+        if (d == 64) attention_f16x2_kernel<64, 2><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+        else attention_f16x2_kernel<32, 2><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+    } else if (planes == 1) {
+        if (d == 64) attention_f16x2_kernel<64, 1><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+        else attention_f16x2_kernel<32, 1><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
     } else {
         if (d == 64) attention_kernel<64><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
         else attention_kernel<32><<<g, 256, 0, s>>>(qkv, out, C, N, scale);

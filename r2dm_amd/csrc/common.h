@@ -74,12 +74,21 @@ struct ConvParams {
     int prologue;        // Prologue
     int algo = ALGO_F32; // ConvAlgo (must match the packing of `w`)
     int pieces = 3;      // ALGO_BF16X3: bf16 pieces per fp32 operand (3 = exact split, 6 products; the 2-piece variant of
-                         // round 1 is superseded by ALGO_F16X2 and no longer dispatched)
+                         // round 1 is superseded by ALGO_F16X2 and no longer dispatched).  ALGO_F16X2 / ALGO_P1F16: 1 = the h plane
+                         // alone, one fp16 product per MAC (the reduced-precision bulk mode); anything else = the split arithmetic
     int sign_shift = 0;  // ALGO_BF16X3 shallow kernel: accumulator sign flips every 2^sign_shift chunks (set by the launcher)
     // optional fused GroupNorm statistics of the OUTPUT (for the GroupNorm that consumes it): per (sample, group)
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
     double* stat = nullptr;
     int stat_G = 0, stat_goff = 0, stat_cpg = 0, stat_slots = 0;
+    // ... and, beside every (sum, sum of squares) slot, the largest |output| that went into it: [B][stat_G][stat_slots] floats
+    // (or an upper bound of it: a wave writes the maximum over ALL its channels into each of its groups' slots).  The consuming
+    // GroupNorm turns it into the observed bound |a| max|x| + |d| on its output (gn_finalize) -- the fp16 range guard of the
+    // split-operand convolutions is data-driven, not a worst-case estimate.  nullptr: not recorded.
+    float* stat_max = nullptr;
+    // optional device scalar multiplied into the matrix product before the bias: the inverse of the power-of-two scale the
+    // fp16 packers apply to a layer's weights (f16x2.h: max|w| is brought to [2^9, 2^10) so that tiny weights keep 22 bits)
+    const float* wscale = nullptr;
     // optional: range[1] takes the running maximum of |output| as float bits -- the engine asks for it when the consumer runs on
     // the fp16 matrix pipe with no GroupNorm in between (a down-sampling convolution; the attention core behind the qkv projection)
     int* range = nullptr;
@@ -104,11 +113,14 @@ hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s);
 bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
 long conv_f16x2_packed_floats(int Cin, int Cout);
 // range_flag (device int, may be nullptr): bit 0 is set if a weight does not fit the fp16 range
-hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s);
+// wscale (device float[2], may be nullptr = unscaled): [0] scratch (max|w| as float bits), [1] <- the inverse of the power-of-two
+// scale applied to the layer's weights (ConvParams::wscale points there)
+hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr);
+hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream_t s);  // max_bits <- float bits of max|w| (zeroed first)
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s);
 bool proj_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
 long proj_f16x2_packed_floats(int Cin, int Cout);
-hipError_t launch_pack_proj_f16x2(const float* w_oi, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s);
+hipError_t launch_pack_proj_f16x2(const float* w_oi, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr);
 hipError_t launch_proj_f16x2(const ConvParams& p, hipStream_t s);
 
 struct GNParams {
@@ -122,10 +134,11 @@ struct GNParams {
     double* partial;     // scratch [B][G][splits][2]
     float2* aff;         // out [B][C]
     float* stats;        // optional out [B][G][2] (mean, rstd) for tests, may be nullptr
-    // optional device int[2]: [1] takes the running maximum (as float bits) of the bound |gamma'| sqrt(n) + |beta'| on the
-    // normalised, affine-transformed tensor (Samuelson's inequality on a standardised sample) -- ALGO_F16X2 consumers
-    // need it below 65504 ([0]: weight flag of the packer)
+    // optional device int[2]: [1] takes the running maximum (as float bits) of a bound on the normalised, affine-transformed
+    // tensor: the OBSERVED one, |a| max|x| + |d| per channel, when partial_max is given; else Samuelson's worst case
+    // |gamma'| sqrt(n) + |beta'| -- ALGO_F16X2 consumers need it below 65504 ([0]: weight flag of the packer)
     int* range_flag = nullptr;
+    float* partial_max = nullptr;  // [B][G][splits]: largest |x| of every split (written by gn_partial / the convolution epilogues)
 };
 int gn_splits(int B, int groups, long group_elems);
 int conv_stat_slots(int H, int W);  // slots per (sample, group) a convolution's fused statistics occupy
@@ -141,7 +154,8 @@ hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, i
                           hipStream_t s, int* range = nullptr);  // range[1]: running max |output| as float bits (may be nullptr)
 
 // qkv: (B, 3C, N) channel-major [q | k | v]; out (B, C, N)
-hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, bool f16x2 = false);
+// planes: 0 = fp32-input MFMA, 2 = fp16 matrix pipe with split operands, 1 = fp16 matrix pipe, one product (attention.hip)
+hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, int planes = 0);
 bool attention_supported(int C, int heads, int N);
 
 struct EmbedParams {

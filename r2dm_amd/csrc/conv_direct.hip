@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
     const int bpg = p.stat ? p.stat_cpg >> 3 : 1;  // 8-channel blocks per group
     const int S = p.stat_slots >> 1;
     double gs = 0.0, gq = 0.0;
+    float gm = 0.f;  // largest |output| of the group (p.stat_max)
     for (int co0 = 0; co0 < p.Cout; co0 += 8) {
         float acc[8][4];
 #pragma unroll
@@ -246,12 +247,15 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
                 if (p.stat) {
                     gs += (double)((v[0] + v[1]) + (v[2] + v[3]));
                     gq += (double)fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                    if (p.stat_max) gm = fmaxf(fmaxf(gm, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 }
             }
         }
         if (p.stat && ((co0 >> 3) + 1) % bpg == 0) {  // the group's last block: wave totals into the slot grid
             const double ts = wave_sum_f64(gs), tq = wave_sum_f64(gq);
+            const float tm = p.stat_max ? wave_max_f32(gm) : 0.f;
             gs = gq = 0.0;
+            gm = 0.f;
             const int g = p.stat_goff + co0 / p.stat_cpg;
             const int j = tx & 3, hf = (tx >> 2) & 1, tile = 4 * tw + j;
             if (tx < 8 && tile < nTw64) {
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
                 gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot + (size_t)S * hf) * 2);
                 o[0] = tx == 0 ? ts : 0.0;
                 o[1] = tx == 0 ? tq : 0.0;
+                if (p.stat_max) p.stat_max[((size_t)b * p.stat_G + g) * p.stat_slots + slot + (size_t)S * hf] = tx == 0 ? tm : 0.f;
             }
         }
     }

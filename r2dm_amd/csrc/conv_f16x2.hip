@@ -67,10 +67,17 @@ struct F2Div {
 };
 static unsigned f2_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned long long)d) + 1u; }
 
-template <int PRO>
+// NPLK = operand planes in use: 2 = the split arithmetic above (three products per fp32 product: the parity path);
+// 1 = the h plane alone, ONE fp16 product per MAC with fp32 accumulation -- the reduced-precision bulk mode that mirrors the
+// reference's fp16 autocast sampler (/root/reference/sample_and_save.py:70, utils/option.py:49): same packing, same tiles,
+// the l plane is neither fetched, computed nor multiplied.
+template <int PRO, int NPLK>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
-    constexpr int UNITS = 3 * MR * NR, PPW = 3;   // 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager
+    static_assert(NPLK == 1 || NPLK == 2, "planes");
+    // NPLK == 2: 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager.  NPLK == 1: 4 MFMAs per tap; the h
+    // plane is the first 6 pieces of a stage: stager w fetches pieces w and w + 2 (pieces 2 and 3 twice: harmless)
+    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = NPLK == 2 ? 3 : 2;
     constexpr int NL = 8;                         // global loads per chunk of raw pixels (the folded affine comes from an LDS table)
     constexpr int PER_ITER = 3 * PPW + NL;        // VMEM operations a stager issues per chunk
     // a weight stage requested at the start of segment j is due at the end of segment j + RING - 2: this many younger
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         };
 
         // ---- transform: affine, SiLU (same arithmetic as conv_bf16x3_pair_kernel), f16 split, pack ----
-        unsigned xpk[2][NPL][4];
+        unsigned xpk[2][NPLK][4];
         auto xf = [&](RawSet& r, float& qv0, float& qv1, float& qm0, float& qm1, int k, int sl) __attribute__((always_inline)) {
             const int e = k >> 2, i2 = k & 3, eo = e & 1;
             constexpr bool silu = PRO == PRO_AFFINE_SILU;
@@ -289,9 +296,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 }
             } else if (sl == 7) {
 #ifdef F2_NO_XF  // timing ablation (wrong results)
-                xpk[eo][0][i2] = xpk[eo][1][i2] = __float_as_uint(qv0);
+                xpk[eo][0][i2] = xpk[eo][NPLK - 1][i2] = __float_as_uint(qv0);
 #else
-                split_f16x2(qv0, qv1, xpk[eo][0][i2], xpk[eo][1][i2]);
+                if constexpr (NPLK == 2) {
+                    split_f16x2(qv0, qv1, xpk[eo][0][i2], xpk[eo][1][i2]);
+                } else {
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    xpk[eo][0][i2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{qv0, qv1}, f16x2));  // v_cvt_pk_f16_f32 (RNE)
+                }
 #endif
             }
         };
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #pragma unroll
             for (int eo = 0; eo < 2; ++eo)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
+                for (int pl = 0; pl < NPLK; ++pl)
                     *reinterpret_cast<u32x4*>(buf + dsto[2 * half + eo] + pl * (XPL * 16)) =
                         u32x4{xpk[eo][pl][0], xpk[eo][pl][1], xpk[eo][pl][2], xpk[eo][pl][3]};
         };
@@ -346,12 +358,21 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (slot >= 0) return;
 #endif
             // pieces 3w, 3w+1, 3w+2: one M0 set-up, the instruction offset advances the global and the LDS address together
-            {
+            if constexpr (NPLK == 2) {
                 const unsigned char* s3 = src + wave * (PPW * 1024);
                 const unsigned d3 = lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + wave * (PPW * 1024));
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %0, %1\n\t"
                              "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:2048"
+                             :
+                             : "v"(lane16), "s"(s3), "s"(d3)
+                             : "memory", "m0");
+            } else {  // the h plane only (6 KiB at the start of the stage): pieces w and w + 2
+                const unsigned char* s3 = src + wave * 1024;
+                const unsigned d3 = lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + wave * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1\n\t"
                              "global_load_lds_dwordx4 %0, %1 offset:2048"
                              :
                              : "v"(lane16), "s"(s3), "s"(d3)
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     auto frag_first = [&](unsigned wb) __attribute__((always_inline)) {
         auto f = [&](auto PL, auto WW) __attribute__((always_inline)) { frag_rd(xb0, wb, ic<0>{}, ic<0>{}, PL, WW, ic<0>{}); };
         f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{}); f(ic<0>{}, ic<3>{});
-        f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
+        if constexpr (NPLK == 2) { f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{}); }
     };
 
     int e_c = 0;  // chunk within the current tile
@@ -501,14 +522,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             __builtin_amdgcn_s_barrier();
             stamp(4 + ky);
             asm volatile("" ::: "memory");
-        } else {
+        } else if (NPLK == 2) {
             asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one plane: all four fragments of this tap)
         }
         const unsigned wbn = lds_w0 + (unsigned)(((t < 8 ? sigma + (kyn != ky ? 1 : 0) : sigma + 1) & (RING - 1)) * WSTAGE);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
-            const int qq = i / (MR * NR), m = (i / NR) % MR, n = i % NR;
+            const int qq = NPLK == 2 ? i / (MR * NR) : 2, m = (i / NR) % MR, n = i % NR;  // (one plane: the xh wh product only)
             if (i == 4) {
                 asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -540,10 +563,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (i == 1) fr(ic<0>{}, ic<1>{});
             if (i == 2) fr(ic<0>{}, ic<2>{});
             if (i == 3) fr(ic<0>{}, ic<3>{});
-            if (i == 4) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 3)
-            if (i == 5) fr(ic<1>{}, ic<1>{});
-            if (i == 8) fr(ic<1>{}, ic<2>{});  // xl' (its last product was unit 7)
-            if (i == 9) fr(ic<1>{}, ic<3>{});
+            if constexpr (NPLK == 2) {
+                if (i == 4) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 3)
+                if (i == 5) fr(ic<1>{}, ic<1>{});
+                if (i == 8) fr(ic<1>{}, ic<2>{});  // xl' (its last product was unit 7)
+                if (i == 9) fr(ic<1>{}, ic<3>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -564,10 +589,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
     f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
     float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
+    float cmx = 0.f;                  // ... and its largest |output| (p.stat_max)
     float amax_e = 0.f;
     int pe_b = 0, pe_th = 0, pe_tw = 0, pe_cot = 0;
     bool pending = false;
     const float sc_blk = p.scale ? *(gcf)p.scale : 1.0f;
+    const float wsc = p.wscale ? *(gcf)p.wscale : 1.0f;  // inverse of the packer's power-of-two weight scale (exact)
     float* const dump = reinterpret_cast<float*>(smem + RES0) + wave * (RESQ * 1024);
     float* const patch = reinterpret_cast<float*>(smem + PATCH0) + wave * 256;
     auto fresh_lane = [&]() __attribute__((always_inline)) {  // (per-lane constants must not be hoisted across the MFMA stream)
@@ -594,24 +621,27 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             for (int j = 0; j < 4; ++j) dst[k8 * 256 + (j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
     };
     // bias, residual, scale, store, statistics of one turned quarter (t[k8]: 4 consecutive pixels of channel 8 k8 + lane / 8)
-    auto quarter = [&](auto QD, const f32x4 (&t)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+    auto quarter = [&](auto QD, const f32x4 (&t)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4], float& pm) __attribute__((always_inline)) {
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
         const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)(cot * CO_T) * HW);
+        float qm = 0.f;
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
-            f32x4 v = t[k8] + bias_e[m * 4 + k8];
+            f32x4 v = t[k8] * wsc + bias_e[m * 4 + k8];
             if (p.res) v = rv_e[k8] + v;
             v *= sc_blk;  // (1.0f without p.scale: exact)
             (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
-            if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            if (p.range || p.stat_max) qm = fmaxf(fmaxf(qm, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);
             pq[k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
         }
+        pm = qm;
+        if (p.range) amax_e = fmaxf(amax_e, qm);
     };
     auto half_stats = [&](auto M, const float (&s0)[4], const float (&q0)[4], const float (&s1)[4], const float (&q1)[4], int b, int th,
-                          int tw, int cot, int ln) __attribute__((always_inline)) {
+                          int tw, int cot, int ln, float hmax) __attribute__((always_inline)) {
         if (!p.stat) return;
         double st_s[4], st_q[4];
 #pragma unroll
@@ -619,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             st_s[k8] = (double)s0[k8] + (double)s1[k8];
             st_q[k8] = (double)q0[k8] + (double)q1[k8];
         }
-        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * CO_T + decltype(M)::value * 32, wave, ln);
+        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * CO_T + decltype(M)::value * 32, wave, ln, hmax);
     };
     auto range_flush = [&](int ln) __attribute__((always_inline)) {
         if (!p.range) return;
@@ -635,16 +665,17 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         f32x4 t[4];
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + (S - 1) * 1024 + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
-        float ps[4], pq[4];
-        quarter(SS, t, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq);
+        float ps[4], pq[4], pm;
+        quarter(SS, t, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq, pm);
         if (S < 3) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
-        if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
+        if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln, fmaxf(cmx, pm));
         if (S == 2) {
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) { cs[k8] = ps[k8]; cq[k8] = pq[k8]; }
+            cmx = pm;
         }
         if (S == 3) {
-            half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
+            half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln, fmaxf(cmx, pm));
             range_flush(ln);
             pending = false;
         }
@@ -681,7 +712,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #pragma unroll
                     for (int n = 0; n < NR; ++n)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[m][n][r] = __builtin_fmaf(acl[m][n][r], LINV, acc[m][n][r]);
+                        for (int r = 0; r < 16; ++r)
+                            if constexpr (NPLK == 2) acc[m][n][r] = __builtin_fmaf(acl[m][n][r], LINV, acc[m][n][r]);
                 // quarter 0 right away (through the 1 KiB patch, block by block), quarters 1..3 into the LDS area
                 {
                     f32x4 t[4];
@@ -695,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     turn_write(ic<1>{}, dump, ln);
                     turn_write(ic<2>{}, dump + 1024, ln);
                     turn_write(ic<3>{}, dump + 2048, ln);
-                    quarter(ic<0>{}, t, e_b, e_th, e_tw, e_cot, ln, cs, cq);
+                    quarter(ic<0>{}, t, e_b, e_th, e_tw, e_cot, ln, cs, cq, cmx);
                     res_request(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
                 }
                 pe_b = e_b; pe_th = e_th; pe_tw = e_tw; pe_cot = e_cot;
@@ -705,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 // "accumulate" branch is never taken there and would keep all 128 registers alive: an empty definition ends
                 // the old values' lives (no instruction)
                 asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
-                asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
+                if constexpr (NPLK == 2) asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
                 if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
                 // first fragments of the next tile (its chunk 0 sits in x buffer 0, stage 3(q+1) in the ring: published at
                 // this chunk's last barrier); also after the last tile -- harmless, keeps the registers plainly defined
@@ -733,10 +765,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 
 // ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane h / l][tap in row][group][co 64][8 ch] f16 ----
 // range[0] is raised to 1 if a weight does not fit the fp16 range (|w| >= 65504); the packed value saturates.
+// wscale (may be nullptr: unscaled): [0] = float bits of max|w| (launch_weight_absmax), [1] <- the inverse of the power-of-two
+// scale s applied to every weight of the layer (f16x2_weight_scale: max|w| s in [2^9, 2^10); the kernel's epilogue multiplies
+// the matrix product by it -- exact)
 __global__ void pack_conv_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout, int Cin,
-                                       long total, int* __restrict__ range) {
+                                       long total, int* __restrict__ range, float* __restrict__ wscale) {
     using namespace f2;
     __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL
+    float inv = 1.0f;
+    const float ws = wscale ? f16x2_weight_scale(reinterpret_cast<const int*>(wscale)[0], &inv) : 1.0f;
+    if (wscale && blockIdx.x == 0 && threadIdx.x == 0) wscale[1] = inv;
     const int nchunks = Cin / CK;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i;
@@ -755,8 +793,8 @@ __global__ void pack_conv_f16x2_kernel(const float* __restrict__ w, unsigned sho
         const int c = r % nchunks;
         const int cot = r / nchunks;
         const int co = cot * CO_T + col, ci = c * CK + g * 8 + ch;
-        const float v = w[((long)co * Cin + ci) * 9 + ky * 3 + tx];
-        if (!(fabsf(v) < 65504.f) && range) atomicOr(range, 1);
+        const float v = w[((long)co * Cin + ci) * 9 + ky * 3 + tx] * ws;
+        if (!(fabsf(v) < 65504.f) && range) atomicOr(range, 1);  // (scaled: only a non-finite weight gets here)
         unsigned ph, pq;
         split_f16x2(v, v, ph, pq);
         dst[i] = (unsigned short)((pl == 0 ? ph : pq) & 0xffffu);
@@ -782,24 +820,51 @@ bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W) {
 
 long conv_f16x2_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * f2::NPL / 2; }
 
-hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s) {
-    const long total = (long)Cout * Cin * 9 * f2::NPL;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag);
+// max_bits <- float bits of max|w[0 .. n)| (non-negative floats order like their bit patterns; NaN sorts above infinity)
+__global__ void weight_absmax_kernel(const float* __restrict__ w, long n, int* __restrict__ max_bits) {
+    float m = 0.f;
+    bool nan = false;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = fabsf(w[i]);
+        nan |= v != v;
+        m = fmaxf(m, v);
+    }
+    m = wave_max_f32(m);
+    if (__any(nan)) m = __int_as_float(0x7fc00000);
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_int(m));
+}
+
+hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    weight_absmax_kernel<<<blocks, 256, 0, s>>>(w, n, max_bits);
     return hipGetLastError();
 }
 
-template <int PRO>
+hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale) {
+    const long total = (long)Cout * Cin * 9 * f2::NPL;
+    if (wscale) {
+        hipError_t e = launch_weight_absmax(w, (long)Cout * Cin * 9, reinterpret_cast<int*>(wscale), s);
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale);
+    return hipGetLastError();
+}
+
+template <int PRO, int NPLK>
 static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
-    auto kern = conv_f16x2_kernel<PRO>;
+    auto kern = conv_f16x2_kernel<PRO, NPLK>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    static const bool one_tile_blocks = getenv("R2DM_F2_NONPERSISTENT") != nullptr;  // experiments: one tile per block
     const int n_cu = f2_cu_count();
-    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+    const unsigned grid = (unsigned)(tiles < n_cu || one_tile_blocks ? tiles : n_cu);
     const int nCoT = p.Cout / f2::CO_T, nTw = p.W / f2::TW, nTh = p.H / f2::TH;
     const int dmax = nCoT > nTw ? (nCoT > nTh ? nCoT : nTh) : (nTw > nTh ? nTw : nTh);
     if (tiles * dmax >= (1ll << 32)) return hipErrorInvalidValue;  // (F2Div is exact below that)
@@ -816,10 +881,17 @@ hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
     if (p.prof != nullptr) return hipErrorInvalidValue;
 #endif
     const long tiles = (long)(p.Cout / f2::CO_T) * (p.W / f2::TW) * (p.H / f2::TH) * p.B;
+    if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
+        switch (p.prologue) {
+            case PRO_NONE: return launch_f2<PRO_NONE, 1>(p, tiles, s);
+            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 1>(p, tiles, s);
+            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 1>(p, tiles, s);
+        }
+    }
     switch (p.prologue) {
-        case PRO_NONE: return launch_f2<PRO_NONE>(p, tiles, s);
-        case PRO_AFFINE: return launch_f2<PRO_AFFINE>(p, tiles, s);
-        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU>(p, tiles, s);
+        case PRO_NONE: return launch_f2<PRO_NONE, 2>(p, tiles, s);
+        case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2>(p, tiles, s);
+        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2>(p, tiles, s);
     }
     return hipErrorInvalidValue;
 }

@@ -50,10 +50,10 @@ struct ConvLayer {
     // second packing of the same weights for ALGO_F16X2 (conv_f16x2.hip): the residual blocks' 3x3 convolutions, whose
     // input is GroupNorm-normalised; selected per launch by the handle's precision mode (r2dm_set_conv_pieces)
     bool f2 = false;
-    size_t w_f2 = 0;
+    size_t w_f2 = 0, ws_f2 = 0;  // ws_*: two floats -- [0] max|w| (packer scratch), [1] inverse of the packer's power-of-two weight scale
     // ... and for ALGO_P1F16 (proj_f16x2.hip): the 1x1 projections of the attention block
     bool p1 = false;
-    size_t w_p1 = 0;
+    size_t w_p1 = 0, ws_p1 = 0;
     size_t packed_elems() const { return (size_t)conv_packed_floats(algo, cin, cout, taps, co_tile, cin_pad); }
 };
 
@@ -110,9 +110,12 @@ struct r2dm_handle {
     ConvLayer in_conv_c;
     size_t cmap = 0, zero_bias = 0;
     bool cmap_ready = false;
-    // split of the fp32 operands of the 3x3 convolutions on the matrix pipe (r2dm_set_conv_pieces): 2 = fp16 + scaled fp16
-    // residual (ALGO_F16X2) wherever a second packing exists, three bf16 pieces elsewhere; 3 = three bf16 pieces everywhere
+    // split of the fp32 operands of the convolutions on the matrix pipe (r2dm_set_conv_pieces): 2 = fp16 + scaled fp16
+    // residual (ALGO_F16X2 / ALGO_P1F16) wherever a second packing exists, three bf16 pieces elsewhere; 3 = three bf16 pieces
+    // everywhere; 1 = the kernels of mode 2 with the fp16 piece alone (one product per MAC: reduced precision, bulk sampling)
     int conv_pieces = 2;
+    bool f16_path() const { return conv_pieces != 3; }  // operands go through fp16: their range is guarded
+    bool flags_fresh = false;  // the blob's range flags have been cleared since the last r2dm_bind_blob (first load does it)
     size_t range_flag = 0;  // blob slot (two ints, ALGO_F16X2): [0] != 0: a weight outside the fp16 range; [1]: float bits of the
                             // largest GroupNorm output bound seen since the last r2dm_check_range
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
@@ -176,10 +179,12 @@ struct r2dm_handle {
         if (L.algo == ALGO_BF16X3 && H > 0 && conv_f16x2_supported(cin, cout, L.taps, H, W) && (px_batch / 256) * (cout / 64) >= f2_min_tiles) {
             L.f2 = true;
             L.w_f2 = take((size_t)conv_f16x2_packed_floats(cin, cout));
+            L.ws_f2 = take(2);
         }
         if (L.algo == ALGO_F32 && H > 0 && proj_f16x2_supported(cin, cout, L.taps, H, W)) {
             L.p1 = true;
             L.w_p1 = take((size_t)proj_f16x2_packed_floats(cin, cout));
+            L.ws_p1 = take(2);
         }
         slots.push_back({wkey, (int64_t)cout * cin * L.taps, SLOT_CONV, L.w, L});
         L.b = raw(bkey, cout);
@@ -391,6 +396,7 @@ struct Ctx {
     // Sink from its epilogue; the GroupNorm then only runs the finalize kernel (no extra pass over the tensor).
     struct Sink {
         double* p = nullptr;
+        float* pm = nullptr;            // largest |output| beside every slot (ConvParams::stat_max): the observed range bound
         int C = 0, cpg = 0, slots = 0;  // C: channels of the normalised (possibly concatenated) tensor
         bool incomplete = false;        // a producer could not emit its share: the consumer runs the streaming pass instead
         explicit operator bool() const { return p != nullptr && !incomplete; }
@@ -405,7 +411,8 @@ struct Ctx {
         k.C = C_total;
         k.cpg = cpg;
         k.slots = conv_stat_slots(H, W);
-        k.p = (double*)ar->alloc((size_t)B * G * k.slots * 2 * sizeof(double));
+        k.p = (double*)ar->alloc((size_t)B * G * k.slots * (2 * sizeof(double) + sizeof(float)));
+        k.pm = (float*)(k.p + (size_t)B * G * k.slots * 2);
         return k;
     }
     void drop_sink(Sink& k) {
@@ -422,7 +429,8 @@ struct Ctx {
         if (!dry()) {
             GNParams g{Src{}, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows, k.p, aff,
                        nullptr};
-            if (h->conv_pieces == 2) g.range_flag = (int*)blob(h->range_flag);  // (only the f16x2 path has a range to guard)
+            g.partial_max = k.pm;
+            if (h->f16_path()) g.range_flag = (int*)blob(h->range_flag);  // (only the fp16 operand paths have a range to guard)
             note(launch_group_norm_finalize(g, k.C, k.slots, st), "group_norm_finalize");
         }
         return aff;
@@ -438,7 +446,8 @@ struct Ctx {
         if (!dry()) {
             GNParams g{x, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows,
                        gn_partial, aff, nullptr};
-            if (h->conv_pieces == 2) g.range_flag = (int*)blob(h->range_flag);  // (only the f16x2 path has a range to guard)
+            g.partial_max = (float*)(gn_partial + (size_t)B * h->cfg.gn_num_groups * 256 * 2);
+            if (h->f16_path()) g.range_flag = (int*)blob(h->range_flag);  // (only the fp16 operand paths have a range to guard)
             note(launch_group_norm(g, st), "group_norm");
         }
         return aff;
@@ -481,19 +490,25 @@ struct Ctx {
             p.prologue = pro;
             // the fp16 split where the input's range is guarded: GroupNorm-normalised (gn_finalize's bound) or tracked by its
             // producer (fir_up2's running maximum)
-            if (L.f2 && h->conv_pieces == 2 && (pro != PRO_NONE || input_bounded)) {
+            if (L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded)) {
                 p.algo = ALGO_F16X2;
                 p.w = blob(L.w_f2);
+                p.wscale = blob(L.ws_f2) + 1;
                 p.co_tile = 64;
+                p.pieces = h->conv_pieces;
             }
-            if (L.p1 && h->conv_pieces == 2 && pro != PRO_AFFINE_SILU && (pro != PRO_NONE || input_bounded)) {
+            if (L.p1 && h->f16_path() && pro != PRO_AFFINE_SILU && (pro != PRO_NONE || input_bounded)) {
                 p.algo = ALGO_P1F16;
                 p.w = blob(L.w_p1);
+                p.wscale = blob(L.ws_p1) + 1;
                 p.co_tile = 64;
+                p.pieces = h->conv_pieces;
             }
-            if (track_out && h->conv_pieces == 2 && p.algo != ALGO_DIRECT) p.range = (int*)blob(h->range_flag);
+            // (every MFMA kernel records the maximum; the direct kernels' outputs never feed an fp16 operand unnormalised)
+            if (track_out && h->f16_path() && p.algo != ALGO_DIRECT) p.range = (int*)blob(h->range_flag);
             if (fused_stats) {
                 p.stat = sink->p;
+                p.stat_max = sink->pm;
                 p.stat_G = h->cfg.gn_num_groups;
                 p.stat_goff = goff;
                 p.stat_cpg = sink->cpg;
@@ -562,11 +577,11 @@ struct Ctx {
         float2* aff = norm(in_stats, src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
         // precision mode 2: the attention core runs on the fp16 matrix pipe (attention.hip) and needs |q|, |k|, |v| < 65504: the
         // projection's epilogue records max|qkv| in the range flag
-        const bool f2 = h->conv_pieces == 2;
+        const bool f2 = h->f16_path();
         Tensor qkv = conv(a.qkv, src1(x), x.H, x.W, PRO_AFFINE, aff, nullptr, 0, false, nullptr, nullptr, 0, false, false, f2);
         ar->release(aff);
         Tensor o = make(a.C, x.H, x.W);
-        if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st, f2), "attention");
+        if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st, f2 ? h->conv_pieces : 0), "attention");
         drop(qkv);
         // (the core's output is a convex combination of v: |o| <= max|qkv|, which the qkv epilogue has recorded)
         Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff, false, f2, track_out);
@@ -605,8 +620,8 @@ struct Ctx {
                 dst = out;
                 goff = out_goff;
             }
-            const bool tf = h->conv_pieces == 2 && last && ((s.out_tracked) || (s.track_final && !s.attn && !s.up));
-            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, tf, i == 0 && s.skip_in_bounded && h->conv_pieces == 2);
+            const bool tf = h->f16_path() && last && ((s.out_tracked) || (s.track_final && !s.attn && !s.up));
+            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, tf, i == 0 && s.skip_in_bounded && h->f16_path());
             if (carry_owned) drop_sink(carry);
             if (have) drop(cur);
             cur = nxt;
@@ -615,7 +630,7 @@ struct Ctx {
             carry_owned = next.p != nullptr;
         }
         if (s.attn) {
-            Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff, s.track_final && !s.up && h->conv_pieces == 2);
+            Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff, s.track_final && !s.up && h->f16_path());
             if (carry_owned) drop_sink(carry);
             carry_owned = false;
             drop(cur);
@@ -624,10 +639,10 @@ struct Ctx {
         if (carry_owned) drop_sink(carry);
         if (s.up) {
             Tensor u = make(s.cout, 2 * H, 2 * W);
-            const bool track = s.uconv.f2 && h->conv_pieces == 2;  // the f16x2 convolution below needs max|u| < 65504
+            const bool track = s.uconv.f2 && h->f16_path();  // the fp16-operand convolution below needs max|u| < 65504
             if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? (int*)blob(h->range_flag) : nullptr), "fir_up2");
             drop(cur);
-            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track, s.track_final && h->conv_pieces == 2);
+            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track, s.track_final && h->f16_path());
             drop(u);
         }
         return cur;
@@ -640,7 +655,7 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     const int H = c.height, W = c.width, T = c.temb_channels;
     float* act = (float*)ar.alloc((size_t)2 * B * T * sizeof(float));  // [SiLU(temb) | hidden scratch]
     float* proj = (float*)ar.alloc((size_t)B * h->ada_rows * sizeof(float));
-    k.gn_partial = (double*)ar.alloc((size_t)B * c.gn_num_groups * 256 * 2 * sizeof(double));
+    k.gn_partial = (double*)ar.alloc((size_t)B * c.gn_num_groups * 256 * (2 * sizeof(double) + sizeof(float)));  // sums | maxima
     k.proj = proj;
     if (!k.dry()) {
         EmbedParams e{cond, k.blob(h->freqs), k.blob(h->w1), k.blob(h->b1), k.blob(h->w2), k.blob(h->b2), act,
@@ -695,9 +710,9 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2);
     k.drop(h0);
     k.drop_sink(s_d1);
-    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2, S[0].out_tracked && h->conv_pieces == 2);
-    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2, S[1].out_tracked && h->conv_pieces == 2);
-    Tensor h4 = k.stage(S[3], src1(h3), H / 4, W / 4, Ctx::Sink{}, &s_u4, 0, S[2].out_tracked && h->conv_pieces == 2);
+    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2, S[0].out_tracked && h->f16_path());
+    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2, S[1].out_tracked && h->f16_path());
+    Tensor h4 = k.stage(S[3], src1(h3), H / 4, W / 4, Ctx::Sink{}, &s_u4, 0, S[2].out_tracked && h->f16_path());
     Tensor u = k.stage(S[4], src1(h4), H / 8, W / 8, s_u4, &s_u3, 0);
     k.drop(h4);
     k.drop_sink(s_u4);
@@ -754,7 +769,7 @@ int check_config(const r2dm_config& c) {
 extern "C" {
 
 const char* r2dm_last_error(void) { return g_err; }
-const char* r2dm_version(void) { return "r2dm_hip 0.2 (gfx950)"; }
+const char* r2dm_version(void) { return "r2dm_hip 0.3 (gfx950)"; }
 
 int r2dm_create(r2dm_handle** out, const r2dm_config* cfg) {
     if (!out || !cfg) return fail(1, "null argument");
@@ -790,7 +805,10 @@ int r2dm_bind_blob(r2dm_handle* h, void* blob, size_t bytes) {
     if ((uintptr_t)blob & (kAlign - 1)) return fail(1, "blob must be %zu-byte aligned", kAlign);
     h->blob = (float*)blob;
     h->cmap_ready = false;
-    HIP_TRY(hipMemset(h->blob + h->range_flag, 0, 2 * sizeof(int)));
+    // The range flags travel WITH the blob: [0] (a weight outside the fp16 range, raised by the packers) must survive a bind
+    // on another rank, and nothing here may touch device memory behind the caller's streams.  A blob that is filled through
+    // r2dm_load_tensor gets both flags cleared by the first load after this bind, on the packing stream.
+    h->flags_fresh = false;
     return 0;
 }
 
@@ -809,12 +827,12 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (v[0] != 0)
-        return fail(2, "a convolution weight is outside the fp16 range (|w| >= 65504) of the f16x2 convolution path; select the "
-                       "bf16x3 split with r2dm_set_conv_pieces(h, 3)");
+        return fail(2, "a convolution weight is not finite (the fp16 packings scale every layer into the fp16 range, so only inf / nan "
+                       "get here); the weights are not usable");
     if (!(bound < 65504.f))
-        return fail(2, "an input of the f16x2 convolution path may be outside the fp16 range (65504): largest GroupNorm output bound "
-                       "(|gamma'| sqrt(n) + |beta'|) / up-sampled activation seen = %.3g; results of this forward are not valid; "
-                       "select the bf16x3 split with r2dm_set_conv_pieces(h, 3)", (double)bound);
+        return fail(2, "an input of the fp16-operand convolution path is outside the fp16 range (65504): largest observed bound "
+                       "(GroupNorm outputs: |a| max|x| + |d| from the producers' recorded maxima; raw inputs: max|x|) = %.3g; results of "
+                       "this forward are not valid; select the bf16x3 split with r2dm_set_conv_pieces(h, 3)", (double)bound);
     return 0;
 }
 
@@ -825,15 +843,21 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
     const Slot& s = h->slots[i];
     if (numel != s.numel) return fail(1, "%s: expected %lld elements, got %lld", s.key.c_str(), (long long)s.numel, (long long)numel);
     hipStream_t st = (hipStream_t)stream;
+    if (!h->flags_fresh) {  // first load into a freshly bound blob: both range flags start from zero, ordered before the packers
+        HIP_TRY(hipMemsetAsync(h->blob + h->range_flag, 0, 2 * sizeof(int), st));
+        h->flags_fresh = true;
+    }
     if (s.kind == SLOT_RAW) {
         HIP_TRY(hipMemcpyAsync(h->blob + s.off, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         HIP_TRY(launch_pack_conv(src, h->blob + s.off, s.conv.cout, s.conv.cin, s.conv.taps, s.conv.co_tile,
                                  s.conv.cin_pad, st, s.conv.algo, s.conv.src_cin, s.conv.src_off));
         if (s.conv.f2)
-            HIP_TRY(launch_pack_conv_f16x2(src, h->blob + s.conv.w_f2, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st));
+            HIP_TRY(launch_pack_conv_f16x2(src, h->blob + s.conv.w_f2, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st,
+                                           h->blob + s.conv.ws_f2));
         if (s.conv.p1)
-            HIP_TRY(launch_pack_proj_f16x2(src, h->blob + s.conv.w_p1, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st));
+            HIP_TRY(launch_pack_proj_f16x2(src, h->blob + s.conv.w_p1, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st,
+                                           h->blob + s.conv.ws_p1));
     }
     h->cmap_ready = false;  // (any reload: cheap to recompute)
     return 0;
@@ -895,7 +919,9 @@ int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t
 static int g_single_kernel_pieces = 2;  // r2dm_conv2d_ring (per-op tests)
 
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces) {
-    if (pieces != 2 && pieces != 3) return fail(1, "pieces must be 2 (fp16 + scaled fp16 residual where the input is normalised; default) or 3 (three bf16 pieces everywhere)");
+    if (pieces < 1 || pieces > 3)
+        return fail(1, "pieces must be 2 (fp16 + scaled fp16 residual: the default parity mode), 3 (three bf16 pieces: fp32 operand range) or "
+                       "1 (one fp16 product per MAC: reduced precision)");
     if (h)
         h->conv_pieces = pieces;
     else
@@ -975,18 +1001,21 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.algo = conv_pick_algo(cin, cout, p.taps);
     if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale)) p.algo = ALGO_F32;  // plain convolutions only
     // per-op tests: with pieces = 2 every shape the f16x2 kernel covers goes there (the engine restricts it to normalised inputs)
-    if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces == 2 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
-    if (p.algo == ALGO_F32 && g_single_kernel_pieces == 2 && prologue != PRO_AFFINE_SILU && proj_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_P1F16;
+    if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces != 3 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
+    if (p.algo == ALGO_F32 && g_single_kernel_pieces != 3 && prologue != PRO_AFFINE_SILU && proj_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_P1F16;
+    if (p.algo == ALGO_F16X2 || p.algo == ALGO_P1F16) p.pieces = g_single_kernel_pieces;
     p.co_tile = (p.algo == ALGO_F16X2 || p.algo == ALGO_P1F16) ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
     p.CinPad = p.algo != ALGO_F32 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
-    if (p.algo == ALGO_F16X2) {  // the range flag: the last int of the scratch (r2dm_conv_packed_elems reserves it)
-        int* flag = (int*)(w_packed + conv_f16x2_packed_floats(cin, cout));
-        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
-        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, flag, st));
+    if (p.algo == ALGO_F16X2) {  // the range flag and the weight scale: behind the packed weights (r2dm_conv_packed_elems reserves 64 floats)
+        float* tail = w_packed + conv_f16x2_packed_floats(cin, cout);
+        HIP_TRY(hipMemsetAsync(tail, 0, sizeof(int), st));
+        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, (int*)tail, st, tail + 2));
+        p.wscale = tail + 3;
     } else if (p.algo == ALGO_P1F16) {
-        int* flag = (int*)(w_packed + proj_f16x2_packed_floats(cin, cout));
-        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
-        HIP_TRY(launch_pack_proj_f16x2(w, w_packed, cout, cin, flag, st));
+        float* tail = w_packed + proj_f16x2_packed_floats(cin, cout);
+        HIP_TRY(hipMemsetAsync(tail, 0, sizeof(int), st));
+        HIP_TRY(launch_pack_proj_f16x2(w, w_packed, cout, cin, (int*)tail, st, tail + 2));
+        p.wscale = tail + 3;
     } else {
         HIP_TRY(launch_pack_conv(w, w_packed, cout, cin, p.taps, p.co_tile, p.CinPad, st, p.algo));
     }
@@ -1011,7 +1040,7 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     return 0;
 }
 
-size_t r2dm_group_norm_scratch_bytes(int32_t B, int32_t groups) { return (size_t)B * groups * 256 * 2 * sizeof(double); }
+size_t r2dm_group_norm_scratch_bytes(int32_t B, int32_t groups) { return (size_t)B * groups * 256 * (2 * sizeof(double) + sizeof(float)); }
 
 int r2dm_group_norm_affine(const float* x, const float* gamma, const float* beta, const float* ada, void* scratch,
                            float* aff, float* stats, int32_t B, int32_t C, int32_t H, int32_t W, int32_t groups,
@@ -1019,6 +1048,7 @@ int r2dm_group_norm_affine(const float* x, const float* gamma, const float* beta
     if (!x || !scratch || !aff) return fail(1, "null argument");
     GNParams g{Src{x, nullptr, C, 0, (long)C * H * W, 0}, B, H, W, groups, eps, gamma, beta, ada, 2L * C,
                (double*)scratch, (float2*)aff, stats};
+    g.partial_max = (float*)((double*)scratch + (size_t)B * groups * 256 * 2);
     HIP_TRY(launch_group_norm(g, (hipStream_t)stream));
     return 0;
 }
@@ -1041,7 +1071,7 @@ int r2dm_fir_up2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int3
 
 int r2dm_attention(const float* qkv, float* out, int32_t B, int32_t C, int32_t heads, int32_t N, void* stream) {
     if (!attention_supported(C, heads, N)) return fail(1, "attention: unsupported shape C=%d heads=%d N=%d", C, heads, N);
-    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream, g_single_kernel_pieces == 2));  // (per-op tests cover both)
+    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream, g_single_kernel_pieces == 3 ? 0 : g_single_kernel_pieces));  // (per-op tests cover all three)
     return 0;
 }
 

@@ -15,6 +15,25 @@ namespace f2 {
 constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 }
 
+// Power-of-two scale of a layer's weights for the fp16 packings: max|w| s in [2^9, 2^10).  The split v = h + 2^-11 l has an
+// ABSOLUTE floor (l leaves the fp16 normals once |v - h| < 2^-25, i.e. below |v| ~ 1e-4: representation error ~1.5e-11
+// absolute), which is 1e-6 RELATIVE for weights of 1e-5 -- a trained zero-initialised convolution
+// (/root/reference/models/ops.py:9-11).  Scaled, every weight within 2^-23 of the layer's largest keeps all 22 bits, and
+// the inverse (exact) goes into the epilogue.  max_bits = float bits of max|w|; returns s, *inv = 1 / s.
+__host__ __device__ __forceinline__ float f16x2_weight_scale(int max_bits, float* inv) {
+    int e = (max_bits >> 23) & 0xff;  // biased exponent of the maximum
+    if (e == 0 || e == 255) {         // all zero (or subnormal) / not finite: unscaled
+        *inv = 1.0f;
+        return 1.0f;
+    }
+    e = e < 20 ? 20 : e > 240 ? 240 : e;
+    union { int i; float f; } s, r;
+    s.i = (263 - e) << 23;  // 2^(9 - (e - 127))
+    r.i = (e - 9) << 23;    // 2^((e - 127) - 9)
+    *inv = r.f;
+    return s.f;
+}
+
 // MODE.FP16_OVFL: f16 conversions of this wave saturate at +-65504 instead of producing inf
 __device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
 

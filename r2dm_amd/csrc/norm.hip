@@ -23,7 +23,7 @@ __device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }
 // grid = (splits, G, B).  Group g of sample b = cpg consecutive planes (all inside one of the two
 // sources), i.e. n = cpg*HW contiguous floats; split s reduces elements [s*len, (s+1)*len).
 __global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(Src x, int cpg, long hw, int splits,
-                                                                double* __restrict__ partial) {
+                                                                double* __restrict__ partial, float* __restrict__ partial_max) {
     const int s = blockIdx.x, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
     const long n = (long)cpg * hw;
     const float* base = x.plane(b, g * cpg, hw);
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(Src x, int cpg, 
     len = (len + 3) & ~3L;
     const long lo = s * len, hi = lo + len < n ? lo + len : n;
     double sum = 0.0, sq = 0.0;
+    float amax = 0.f;  // largest |x| of the split (the consumer's observed range bound)
     const bool vec = ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && ((n & 3) == 0);
     if (vec) {
         const f32x4* p4 = reinterpret_cast<const f32x4*>(base);
@@ -42,31 +43,39 @@ __global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(Src x, int cpg, 
                 sum += d;
                 sq = fma(d, d, sq);
             }
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     } else {
         for (long i = lo + threadIdx.x; i < hi; i += kGnThreads) {
             const float v = base[i];
             sum += (double)v;
             sq += (double)v * (double)v;
+            amax = fmaxf(amax, fabsf(v));
         }
     }
     __shared__ double red[2][kGnThreads / 64];
+    __shared__ float redm[kGnThreads / 64];
     sum = wave_sum(sum);
     sq = wave_sum(sq);
+    amax = wave_max_f32(amax);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = sum;
         red[1][threadIdx.x >> 6] = sq;
+        redm[threadIdx.x >> 6] = amax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0.0, q = 0.0;
+        float m = 0.f;
         for (int w = 0; w < kGnThreads / 64; ++w) {
             a += red[0][w];
             q += red[1][w];
+            m = fmaxf(m, redm[w]);
         }
         double* o = partial + (((long)b * G + g) * splits + s) * 2;
         o[0] = a;
         o[1] = q;
+        if (partial_max) partial_max[((long)b * G + g) * splits + s] = m;
     }
 }
 
@@ -78,9 +87,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ ada, long ada_stride,
                                                          float2* __restrict__ aff, float* __restrict__ stats,
-                                                         int* __restrict__ range_flag) {
+                                                         int* __restrict__ range_flag, const float* __restrict__ partial_max) {
     const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x;
     const double* p = partial + ((long)b * G + g) * splits * 2;
+    // the largest |x| of the group as its producers observed it (range guard of the fp16 consumers; any order: a maximum)
+    float gmax = 0.f;
+    if (range_flag && partial_max) {
+        const float* pm = partial_max + ((long)b * G + g) * splits;
+        for (int s = threadIdx.x; s < splits; s += 256) gmax = fmaxf(gmax, pm[s]);
+        gmax = wave_max_f32(gmax);
+    }
     // fixed thread -> slot assignment: deterministic.  All of a thread's slots are requested before the first is added (16-byte
     // loads, up to 8 in flight): as a plain loop the <= 8 dependent round trips to L2 were most of this 5 us kernel
     using d2 = __attribute__((ext_vector_type(2))) double;
@@ -100,15 +116,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         }
     }
     __shared__ double red[2][4];
+    __shared__ float redm[4];
     sum = wave_sum(sum);
     sq = wave_sum(sq);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = sum;
         red[1][threadIdx.x >> 6] = sq;
+        redm[threadIdx.x >> 6] = gmax;
     }
     __syncthreads();
     sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    gmax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
     const double n = (double)cpg * (double)hw;
     const double mean_d = sum / n;
     double var_d = sq / n - mean_d * mean_d;
@@ -131,10 +150,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         }
         const float a = rstd * w;
         aff[(long)b * C + c] = make_float2(a, sh - mean * a);
-        // |a (x - mean) + sh| <= |w| sqrt(n) + |sh| for every element of the group (Samuelson); SiLU only shrinks it
+        // Range guard of the fp16 consumers: a bound on |a x + d| over the group.  With the producers' observed max|x|:
+        // |a| max|x| + |d| -- data-driven: it trips only if the data could really reach the limit.  Without it (no producer
+        // recorded a maximum): |a (x - mean) + sh| <= |w| sqrt(n) + |sh| (Samuelson's worst case).  SiLU only shrinks either.
         // (recorded as a running maximum -- positive floats order like their bit patterns, NaN above all -- and compared
         // with the fp16 limit by r2dm_check_range)
-        if (range_flag) atomicMax(range_flag + 1, __float_as_int(fabsf(w) * (float)sqrt(n) + fabsf(sh)));
+        if (range_flag) {
+            const float d = sh - mean * a;
+            const float bound = partial_max ? fabsf(a) * gmax + fabsf(d) : fabsf(w) * (float)sqrt(n) + fabsf(sh);
+            atomicMax(range_flag + 1, __float_as_int(bound));
+        }
     }
 }
 
@@ -155,16 +180,16 @@ hipError_t launch_group_norm(const GNParams& p, hipStream_t st) {
     if (p.x.c1 > 0 && (p.x.c0 % cpg)) return hipErrorInvalidValue;  // a group may not straddle the concat seam
     const long hw = (long)p.H * p.W;
     const int splits = gn_splits(p.B, p.groups, cpg * hw);
-    gn_partial_kernel<<<dim3(splits, p.groups, p.B), kGnThreads, 0, st>>>(p.x, cpg, hw, splits, p.partial);
+    gn_partial_kernel<<<dim3(splits, p.groups, p.B), kGnThreads, 0, st>>>(p.x, cpg, hw, splits, p.partial, p.partial_max);
     gn_finalize_kernel<<<dim3(p.groups, p.B), 256, 0, st>>>(p.partial, splits, C, cpg, hw, p.eps, p.gamma, p.beta,
-                                                            p.ada, p.ada_stride, p.aff, p.stats, p.range_flag);
+                                                            p.ada, p.ada_stride, p.aff, p.stats, p.range_flag, p.partial_max);
     return hipGetLastError();
 }
 
 hipError_t launch_group_norm_finalize(const GNParams& p, int C, int splits, hipStream_t st) {
     if (C % p.groups) return hipErrorInvalidValue;
     gn_finalize_kernel<<<dim3(p.groups, p.B), 256, 0, st>>>(p.partial, splits, C, C / p.groups, (long)p.H * p.W, p.eps, p.gamma,
-                                                            p.beta, p.ada, p.ada_stride, p.aff, p.stats, p.range_flag);
+                                                            p.beta, p.ada, p.ada_stride, p.aff, p.stats, p.range_flag, p.partial_max);
     return hipGetLastError();
 }
 

@@ -33,7 +33,9 @@ constexpr int PATCH0 = 2 * XPL + 2 * WPL;
 constexpr int LDS_TOTAL = PATCH0 + 4 * 1024;  // 55 296
 }  // namespace p1
 
-template <int PRO>
+// NPLK = operand planes in use: 2 = the split arithmetic (parity path), 1 = the h plane alone: one fp16 product per MAC, the
+// reduced-precision bulk mode (conv_f16x2.hip); the l planes are then neither written nor read.
+template <int PRO, int NPLK>
 __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) {
     using namespace p1;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) 
         }
         const unsigned char* ws = wsrc + (size_t)c * (2 * CO_T * CKP * 2);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) wv[u] = *(gcu4)(ws + (size_t)(tid + 256 * u) * 16);
+        for (int u = 0; u < NPLK; ++u) wv[u] = *(gcu4)(ws + (size_t)(tid + 256 * u) * 16);
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -87,16 +89,16 @@ __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) 
                     v0 = v0 * ad4[i2][0] + ad4[i2][1];
                     v1 = v1 * ad4[i2][2] + ad4[i2][3];
                 }
-                split_f16x2(v0, v1, ph[i2], pl[i2]);
+                split_f16x2(v0, v1, ph[i2], pl[i2]);  // (NPLK == 1: the l half is dead code)
             }
             unsigned char* d = smem + (q * 4 + e) * ROWB + cg * 16;
             *reinterpret_cast<u32x4*>(d) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-            *reinterpret_cast<u32x4*>(d + XPL) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+            if (NPLK == 2) *reinterpret_cast<u32x4*>(d + XPL) = u32x4{pl[0], pl[1], pl[2], pl[3]};
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // 16-byte unit: plane, output channel, 8-channel part
             const int un = tid + 256 * u, plane = un >> 8, r = un & 255;
-            *reinterpret_cast<u32x4*>(smem + 2 * XPL + plane * WPL + (r >> 2) * ROWB + (r & 3) * 16) = wv[u];
+            if (NPLK == 2 || u == 0) *reinterpret_cast<u32x4*>(smem + 2 * XPL + plane * WPL + (r >> 2) * ROWB + (r & 3) * 16) = wv[u];
         }
     };
 
@@ -127,33 +129,46 @@ __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) 
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 wh[m] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(smem + 2 * XPL + (m * 32) * ROWB + wrow + st * 32));
-                wl[m] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(smem + 2 * XPL + WPL + (m * 32) * ROWB + wrow + st * 32));
+                if (NPLK == 2) wl[m] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(smem + 2 * XPL + WPL + (m * 32) * ROWB + wrow + st * 32));
             }
 #pragma unroll
             for (int n = 0; n < NR; ++n) {
                 xh[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(smem + xrow[n] + st * 32));
-                xl[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(smem + XPL + xrow[n] + st * 32));
+                if (NPLK == 2) xl[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(smem + XPL + xrow[n] + st * 32));
             }
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int n = 0; n < NR; ++n) {
-                    acl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[m], xl[n], acl[m][n], 0, 0, 0);
-                    acl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[m], xh[n], acl[m][n], 0, 0, 0);
+                    if (NPLK == 2) {
+                        acl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[m], xl[n], acl[m][n], 0, 0, 0);
+                        acl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[m], xh[n], acl[m][n], 0, 0, 0);
+                    }
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[m], xh[n], acc[m][n], 0, 0, 0);
                 }
         }
     }
-    conv_epilogue_wide<TH, TW, MR, NR, true>(p, acc, acl, b, th, tw, nTw, cot * CO_T, wave, lane,
-                                               reinterpret_cast<float*>(smem + PATCH0) + wave * 256, f2::LINV);
+    const float wsc = p.wscale ? *p.wscale : 1.0f;  // inverse of the packer's power-of-two weight scale (exact)
+    if constexpr (NPLK == 2) {
+        conv_epilogue_wide<TH, TW, MR, NR, true>(p, acc, acl, b, th, tw, nTw, cot * CO_T, wave, lane,
+                                                   reinterpret_cast<float*>(smem + PATCH0) + wave * 256, f2::LINV, wsc);
+    } else {
+        f32x16 none[1][1];
+        conv_epilogue_wide<TH, TW, MR, NR, false>(p, acc, none, b, th, tw, nTw, cot * CO_T, wave, lane,
+                                                    reinterpret_cast<float*>(smem + PATCH0) + wave * 256, 1.0f, wsc);
+    }
 }
 
 // ---- weight packing: (Cout, Cin) fp32 -> [co tile][chunk][plane h / l][co 64][32 ch] f16 ----
 // range[0] is raised to 1 if a weight does not fit the fp16 range (|w| >= 65504); the packed value saturates.
+// wscale: as pack_conv_f16x2_kernel (conv_f16x2.hip) -- the layer's weights are scaled by a power of two, [1] <- its inverse
 __global__ void pack_proj_f16x2_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int Cout, int Cin, long pairs,
-                                       int* __restrict__ range) {
+                                       int* __restrict__ range, float* __restrict__ wscale) {
     using namespace p1;
     f16_saturate_mode();
+    float inv = 1.0f;
+    const float ws = wscale ? f16x2_weight_scale(reinterpret_cast<const int*>(wscale)[0], &inv) : 1.0f;
+    if (wscale && blockIdx.x == 0 && threadIdx.x == 0) wscale[1] = inv;
     const int nchunks = Cin / CKP;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
         long r = i;  // one pair of input channels of one output channel
@@ -164,7 +179,7 @@ __global__ void pack_proj_f16x2_kernel(const float* __restrict__ w, unsigned* __
         const int c = r % nchunks;
         const int cot = r / nchunks;
         const int co = cot * CO_T + col, ci = c * CKP + 2 * cp;
-        const float v0 = w[(long)co * Cin + ci], v1 = w[(long)co * Cin + ci + 1];
+        const float v0 = w[(long)co * Cin + ci] * ws, v1 = w[(long)co * Cin + ci + 1] * ws;
         if ((!(fabsf(v0) < 65504.f) || !(fabsf(v1) < 65504.f)) && range) atomicOr(range, 1);
         unsigned ph, pl;
         split_f16x2(v0, v1, ph, pl);
@@ -179,17 +194,21 @@ bool proj_f16x2_supported(int Cin, int Cout, int taps, int H, int W) {
 }
 long proj_f16x2_packed_floats(int Cin, int Cout) { return (long)Cin * Cout; }
 
-hipError_t launch_pack_proj_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s) {
+hipError_t launch_pack_proj_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale) {
     if (Cin % p1::CKP || Cout % p1::CO_T) return hipErrorInvalidValue;
     const long pairs = (long)Cout * Cin / 2;
+    if (wscale) {
+        hipError_t e = launch_weight_absmax(w, (long)Cout * Cin, reinterpret_cast<int*>(wscale), s);
+        if (e != hipSuccess) return e;
+    }
     const int blocks = (int)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
-    pack_proj_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned*>(dst), Cout, Cin, pairs, range_flag);
+    pack_proj_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned*>(dst), Cout, Cin, pairs, range_flag, wscale);
     return hipGetLastError();
 }
 
-template <int PRO>
+template <int PRO, int NPLK>
 static hipError_t launch_p1(const ConvParams& p, hipStream_t s) {
-    auto kern = proj_f16x2_kernel<PRO>;
+    auto kern = proj_f16x2_kernel<PRO, NPLK>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, p1::LDS_TOTAL);
@@ -206,7 +225,8 @@ hipError_t launch_proj_f16x2(const ConvParams& p, hipStream_t s) {
     if (p.x.p1 && p.x.c0 % 8) return hipErrorInvalidValue;  // a thread's 8 channels must not straddle the concat seam
     if (p.prologue == PRO_AFFINE_SILU || (p.prologue != PRO_NONE && p.aff == nullptr)) return hipErrorInvalidValue;
     if (p.stat && p.stat_slots != conv_stat_slots(p.H, p.W)) return hipErrorInvalidValue;
-    return p.prologue == PRO_NONE ? launch_p1<PRO_NONE>(p, s) : launch_p1<PRO_AFFINE>(p, s);
+    if (p.pieces == 1) return p.prologue == PRO_NONE ? launch_p1<PRO_NONE, 1>(p, s) : launch_p1<PRO_AFFINE, 1>(p, s);
+    return p.prologue == PRO_NONE ? launch_p1<PRO_NONE, 2>(p, s) : launch_p1<PRO_AFFINE, 2>(p, s);
 }
 
 }  // namespace r2dm

@@ -52,6 +52,13 @@ def _range_guard(model):
     return guard() if callable(guard) else contextlib.nullcontext()
 
 
+def _early_range_check(model):
+    """One synchronising range check after the first denoiser call of a long loop (one sync per ``sample`` call)."""
+    check = getattr(model, "check_range", None)
+    if callable(check):
+        check()
+
+
 def _log(t: torch.Tensor, eps: float = 1e-20) -> torch.Tensor:
     return torch.log(t.clamp(min=eps))
 
@@ -323,6 +330,8 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         with _range_guard(self.model):
             for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
                 prediction = self.model(x, cond[i])
+                if i == 0 and num_steps > 8:
+                    _early_range_check(self.model)  # a checkpoint the fp16 operand path cannot run fails now, not after the loop
                 noise = self.randn_like(x, rng=rng)
                 x = self._posterior(x, prediction, noise, coef[i], mode_id)
                 if return_all:

@@ -34,8 +34,13 @@ def count_parameters(model: torch.nn.Module) -> int:
 def _denoiser(cfg: Config, max_batch: int) -> EfficientUNet:
     arch = cfg.model.architecture
     if arch == "refinenet":
-        raise NotImplementedError("architecture='refinenet' (LiDARGen baseline, /root/reference/models/refinenet.py) "
-                                  "is outside the built hot path; see DESIGN.md")
+        # The reference cannot build this architecture through setup_model either: utils/inference.py:36 rebinds
+        # `in_channels` to an int and :54 calls `sum(in_channels)` on it -> "TypeError: 'int' object is not iterable"
+        # (verified by running the reference's setup_model on a refinenet config).  No checkpoint of the LiDARGen
+        # baseline can therefore reach the sampling path this package replaces; the drop-in keeps the reference's
+        # error type and message and says why (branch closed, not built).
+        raise TypeError("'int' object is not iterable  [architecture='refinenet': the reference's setup_model raises this at "
+                        "utils/inference.py:54 (`sum(in_channels)` on an int); LiDARGenRefineNet is not part of the sampling path]")
     if arch != "efficient_unet":
         raise ValueError(f"Unknown: {arch}")
     channels = int(bool(cfg.data.train_depth)) + int(bool(cfg.data.train_reflectance))
@@ -58,7 +63,9 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
 
     ``max_batch`` (extension) tells the HIP engine which batch size to tile its layers for -- per-seed results are
     bit-reproducible for a fixed ``max_batch`` only (different tilings sum in a different order); ``precision``
-    (extension) is ``"fp32"`` (default operand split) or ``"fp32-bf16x3"`` (three bf16 pieces everywhere; see ``EfficientUNet.set_precision``).
+    (extension) is ``"fp32"`` (default: 22-bit split fp16 operands, parity mode), ``"fp32-bf16x3"`` (three bf16 pieces, parity mode with
+    the full fp32 operand range) or ``"fp16"`` (one fp16 product per MAC: the reduced-precision bulk mode that mirrors the reference's
+    fp16 autocast, sample_and_save.py:70; see ``EfficientUNet.set_precision``).
     ``compile=True`` wraps the denoiser in ``torch.compile`` as upstream does; its forward is one ctypes call into the
     HIP library, i.e. a graph break that runs eagerly."""
     if isinstance(ckpt, (str, Path)):

@@ -256,16 +256,31 @@ class EfficientUNet(nn.Module):
             self._engine = _Engine(self.geometry, self.max_batch)
         return self._engine.blob_bytes()
 
-    # -- operand split of the 3x3 convolutions ------------------------------------------------------------
-    PRECISIONS = {"fp32": 2, "fp32-bf16x3": 3}
+    # -- arithmetic of the convolutions / attention on the matrix pipe --------------------------------------
+    PRECISIONS = {"fp32": 2, "fp32-bf16x3": 3, "fp16": 1}
+    _DEPRECATED_PRECISIONS = {"bf16x2": "fp32"}  # round 1's two-piece bf16 mode: the default is now both faster and more accurate
 
     def set_precision(self, precision: str = "fp32"):
-        """Both modes compute fp32 products to fp32 accuracy or better; they differ in how the matrix pipe gets there.
-        ``"fp32"`` (default): the residual blocks' 3x3 convolutions (GroupNorm-normalised input) split every operand into an
-        fp16 piece and a scaled fp16 residual -- three MFMA products, two accumulators (conv_f16x2.hip); the remaining 3x3
-        convolutions use three bf16 pieces / six products.  ``"fp32-bf16x3"``: three bf16 pieces everywhere (full fp32
-        operand range; the round-1 parity mode, about 1.4x slower).  The fp16 path needs |operand| < 65504, which the
-        engine bounds per GroupNorm; ``check_range`` raises if the bound fails."""
+        """``"fp32"`` (default) and ``"fp32-bf16x3"`` are PARITY modes: fp32 tensors, fp32 accumulation, products computed
+        to fp32 accuracy or better; they differ in how the matrix pipe gets there.
+        ``"fp32"``: every 3x3 / 1x1 convolution and the attention core split each fp32 operand to 22 bits into an fp16
+        piece and a 2^11-scaled fp16 residual -- three fp16 MFMA products (the residual x residual term, 2^-22 relative, is
+        dropped), two fp32 accumulators (conv_f16x2.hip, proj_f16x2.hip, attention.hip): fp32-class by measurement (error
+        vs fp64 below an fp32 FMA chain's).  Operands pass through fp16, so |operand| < 65504 is required; weights are
+        pre-scaled per layer by a power of two, activations are guarded by their producers' OBSERVED maxima, and
+        ``check_range`` raises if a forward could have saturated.
+        ``"fp32-bf16x3"``: three bf16 pieces / six products (exact 24-bit operands, fp32 operand range; the round-1 kernels,
+        about 1.6x slower).
+        ``"fp16"`` is the REDUCED-PRECISION bulk mode, the counterpart of the reference's fp16 autocast sampler
+        (/root/reference/sample_and_save.py:70, utils/option.py:49): the same kernels with the fp16 piece alone -- one
+        product per MAC (11-bit operands), fp32 accumulation, fp32 tensors, GroupNorm / softmax / the posterior update in
+        fp32.  It has its own tolerance class (tests/test_hip_fp16_mode.py) and is never the default."""
+        if precision in self._DEPRECATED_PRECISIONS:
+            import warnings
+
+            new = self._DEPRECATED_PRECISIONS[precision]
+            warnings.warn(f"precision={precision!r} is deprecated (round-1 mode, superseded); using {new!r}", DeprecationWarning, stacklevel=2)
+            precision = new
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {precision!r}")
         self.precision = precision
@@ -287,7 +302,10 @@ class EfficientUNet(nn.Module):
         outer, self._defer_range_check = self._defer_range_check, True
         try:
             yield self
-        finally:
+        except BaseException:
+            self._defer_range_check = outer  # (an exception from the loop is not masked by a range error raised on top of it)
+            raise
+        else:
             self._defer_range_check = outer
             if not outer:
                 self.check_range()

@@ -5,9 +5,10 @@ files ``samples_{seed:010d}.pth`` holding a (5,H,W) [depth, x, y, z, reflectance
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N sample_and_save.py ...`` -- one process
 per MI355X, seeds sharded contiguously (what Accelerate's split_batches DataLoader does in the reference,
 :25-46), weights packed once on rank 0 and broadcast over RCCL/xGMI, no collective in the sampling loop.
-Precision: fp32 parity always (the reference runs this script under fp16 autocast, :70; here the parity path is the fast
-one); ``--precision`` only selects how the 3x3 convolutions split their fp32 operands on the matrix pipe
-(``fp32``: fp16 + scaled fp16 residual, default; ``fp32-bf16x3``: three bf16 pieces, fp32 operand range).
+Precision: fp32 parity by default (``--precision fp32``: 22-bit split fp16 operands, three MFMA products per fp32 product;
+``fp32-bf16x3``: three bf16 pieces, fp32 operand range).  The reference runs this script under fp16 autocast (:70,
+utils/option.py:49); ``--precision fp16`` is that bulk mode here: one fp16 product per MAC, fp32 accumulation and tensors,
+its own tolerance class (tests/test_hip_fp16_mode.py).
 ``--max-batch`` / the batch size fix the layer tilings: per-seed results are bit-reproducible for a fixed batch size only."""
 import os
 from argparse import ArgumentParser
@@ -62,5 +63,5 @@ if __name__ == "__main__":
     parser.add_argument("--num_samples", type=int, default=10_000)
     parser.add_argument("--num_steps", type=int, default=256)
     parser.add_argument("--mode", choices=["ddpm", "ddim"], default="ddpm")
-    parser.add_argument("--precision", choices=["fp32", "fp32-bf16x3"], default="fp32")
+    parser.add_argument("--precision", choices=["fp32", "fp32-bf16x3", "fp16"], default="fp32")
     sample(parser.parse_args())

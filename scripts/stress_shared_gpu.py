@@ -37,6 +37,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "hog":
         while time.time() - t0 < secs:
             for _ in range(20): a @ a
             torch.cuda.synchronize()
+    elif kind == "forward":
+        import r2dm_amd
+        from r2dm_amd import synthetic
+        ck = synthetic.synthetic_checkpoint(seed=0, resolution=(64, 1024))
+        ddpm, _, _ = r2dm_amd.setup_model(ck, device=torch.device("cuda", 0), show_info=False, max_batch=2)
+        xx = torch.randn(2, 2, 64, 1024, device="cuda"); cc = torch.full((2,), -3.0, device="cuda")
+        with ddpm.model.deferred_range_check():
+            while time.time() - t0 < secs:
+                for _ in range(10): ddpm.model(xx, cc)
+                torch.cuda.synchronize()
     else:
         c = conv_call("L1_64_64")
         while time.time() - t0 < secs:
@@ -51,7 +61,7 @@ for hog in os.environ.get("HOGS", "none,copy,gemm,conv").split(","):
     p = None
     if hog != "none":
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "hog", hog, "60"])
-        time.sleep(8)  # let it start (import torch) and run
+        time.sleep(30 if hog == "forward" else 8)  # let it start (import torch) and run
     for pieces in (2, 3):
         _lib.check(L.r2dm_set_conv_pieces(None, pieces))
         for name in os.environ.get("SHAPES", "L1_64_64,L3_256_256").split(","):
@@ -62,6 +72,12 @@ for hog in os.environ.get("HOGS", "none,copy,gemm,conv").split(","):
                 y = c()
                 if not torch.equal(y, ref):
                     bad += 1; worst = max(worst, (y - ref).abs().max().item())
+                    if bad <= 3:  # where: (sample, 32-channel block, tile row of 4, 32-column segment) cells that differ
+                        d = (y != ref)
+                        Bq, Cq, Hq, Wq = d.shape
+                        cells = d.view(Bq, Cq // 32, 32, Hq // 4, 4, Wq // 32, 32).any(dim=6).any(dim=4).any(dim=2).nonzero().tolist()
+                        rows = d.view(Bq, Cq, Hq // 4, 4, Wq).any(dim=4).any(dim=1).any(dim=0).any(dim=0).tolist()
+                        print(f"    mismatch {bad}: {int(d.sum())} elements in {len(cells)} cells (b, c/32, h/4, w/32), first {cells[:8]}; rows within the 4-row tile hit: {rows}; max |diff| {(y - ref).abs().max().item():.2e}", flush=True)
             torch.cuda.synchronize()
             print(f"neighbour={hog:5s} pieces={pieces} {name:12s}: {bad:3d} of {iters} launches differ from the first (max |diff| {worst:.2e}); {(time.time() - t0) / iters * 1e6:.0f} us/launch", flush=True)
     if p is not None:

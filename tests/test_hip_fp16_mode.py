@@ -1,0 +1,158 @@
+"""-m gpu: `precision="fp16"` -- the reduced-precision bulk mode.
+
+What the reference does: its bulk sampler runs the whole denoiser under fp16 autocast (/root/reference/sample_and_save.py:70,
+utils/option.py:49 `mixed_precision = "fp16"`): convolutions and matmuls take fp16 operands and accumulate in fp32.
+What this mode does: the SAME kernels as the parity mode with the fp16 piece alone -- one `v_mfma_f32_32x32x16_f16` per 16
+k-values instead of three -- i.e. operands rounded to fp16 (11 significant bits; weights after the packers' power-of-two
+scale, activations after GroupNorm + SiLU), fp32 accumulation, fp32 tensors in HBM, fp32 GroupNorm statistics / softmax /
+posterior update.  It is NOT a parity mode: its tolerance class is stated and asserted here, separately.
+
+Tolerance class.  RNE to fp16 has unit roundoff 2^-11; an operand's relative error is ~uniform, rms 2^-11/sqrt(3) = 2.8e-4
+... 2^-12/sqrt(3) (mantissa dependent), two operands per product and K random-sign products give a relative rms error of a
+convolution output of ~3e-4 independent of K.  Against an emulation that rounds the operands to fp16 in torch and multiplies
+in fp64, the kernel must agree to fp32-accumulation accuracy -- that pins the mode to 'fp16 operands, nothing else lost'."""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import max_abs, rnd, synthetic_ckpt
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")]
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import r2dm_oracle
+
+    return r2dm_oracle
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hipops
+
+    return hipops
+
+
+def rel_rms(a, ref):
+    return ((a.double() - ref.double()).pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt()).item()
+
+
+def f16_round_weights(w):
+    """What the packers store: RNE_f16(w * s) / s with s the power of two that brings max|w| into [2^9, 2^10)."""
+    e = math.floor(math.log2(w.abs().max().item()))
+    s = 2.0 ** (9 - e)
+    return (w.double() * s).half().double() / s
+
+
+@pytest.mark.parametrize("k,cin,cout,h,w", [(3, 64, 64, 16, 256), (3, 128, 256, 8, 128), (3, 512, 512, 8, 128), (1, 256, 768, 8, 128), (1, 512, 512, 8, 128)])
+def test_conv_one_product_is_exactly_fp16_operands(O, H, k, cin, cout, h, w):
+    x, wt, b = rnd(1, 2, cin, h, w), rnd(2, cout, cin, k, k) / math.sqrt(k * k * cin), rnd(3, cout)
+    res = rnd(4, 2, cout, h, w)
+    truth = (res.double() + O.conv_ring(x.double(), wt.double(), b.double())) * 0.70710678
+    emul = (res.double() + O.conv_ring(x.half().double(), f16_round_weights(wt), b.double())) * 0.70710678
+    H.set_conv_pieces(1)
+    try:
+        y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), residual=res.to(DEV), scale=0.70710678).cpu()
+    finally:
+        H.set_conv_pieces(2)
+    e_truth, e_emul = rel_rms(y, truth), max_abs(y, emul)
+    print(f"fp16 mode k={k} {cin}->{cout}: rel rms vs fp64 {e_truth:.2e}; max |y - fp16-operand emulation| {e_emul:.2e}")
+    assert e_emul < 1e-5            # fp32 accumulation of exactly the emulated products
+    assert 3e-5 < e_truth < 6e-4    # ... and really the reduced mode (the parity mode sits at ~2e-7)
+
+
+@pytest.mark.parametrize("pro", [1, 2])
+def test_conv_one_product_with_fused_prologue(O, H, pro):
+    import torch.nn.functional as F
+
+    cin, cout, h, w = 128, 128, 16, 256
+    x, wt, b = rnd(1, 2, cin, h, w), rnd(2, cout, cin, 3, 3) / math.sqrt(9 * cin), rnd(3, cout)
+    aff = torch.stack([torch.rand(2, cin) + 0.5, torch.randn(2, cin) * 0.3], -1).contiguous()
+    xa = x.double() * aff[..., 0].double()[:, :, None, None] + aff[..., 1].double()[:, :, None, None]
+    if pro == 2:
+        xa = F.silu(xa)
+    truth = O.conv_ring(xa, wt.double(), b.double())
+    H.set_conv_pieces(1)
+    try:
+        y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), aff=aff.to(DEV), prologue=pro).cpu()
+    finally:
+        H.set_conv_pieces(2)
+    e = rel_rms(y, truth)
+    print(f"fp16 mode, prologue {pro}: rel rms vs fp64 {e:.2e}")
+    assert 3e-5 < e < 6e-4
+
+
+def test_attention_one_product(H):
+    B, C, N, heads = 2, 512, 1024, 8
+    qkv = rnd(21, B, 3 * C, N)
+    d = C // heads
+    q, k, v = (t.double().reshape(B, heads, d, N) for t in qkv.split(C, 1))
+    p = torch.softmax(torch.einsum("bhdn,bhdm->bhnm", q, k) / math.sqrt(d), -1)
+    truth = torch.einsum("bhnm,bhdm->bhdn", p, v).reshape(B, C, N)
+    H.set_conv_pieces(1)
+    try:
+        y = H.attention(qkv.to(DEV), heads).cpu()
+    finally:
+        H.set_conv_pieces(2)
+    y2 = H.attention(qkv.to(DEV), heads).cpu()
+    e1, e2 = rel_rms(y, truth), rel_rms(y2, truth)
+    print(f"attention: fp16 mode rel rms {e1:.2e}; parity mode {e2:.2e}")
+    assert e2 < 1e-6 and 1e-5 < e1 < 3e-3
+
+
+def test_unet_and_sampler_tolerance_class(O):
+    """The stated tolerance class of the mode, measured at 64x1024 (synthetic untrained network, the hardest case: its gains are
+    higher than a trained one's):
+      U-Net forward vs the fp64 oracle      rel rms < 3e-3   (parity mode: ~1e-7; an fp16-autocast torch forward: same class)
+      48-step DDPM final sample vs the parity mode on the same noise   rms < 2e-2 on a [-1, 1] range image, and the
+      clamped samples agree in 99 % of the pixels to 5e-2.
+    Switching back restores the parity mode bit for bit; the mode is never the default."""
+    import r2dm_amd
+
+    ck = synthetic_ckpt()
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    assert ddpm.model.precision == "fp32"
+    x, c = rnd(70, 2, 2, 64, 1024).to(DEV), torch.tensor([-3.0, 2.0], device=DEV)
+    sd = {k: v.double().to(DEV) for k, v in O.strip_prefix(ck["ema_weights"]).items()}
+    truth = O.unet_forward(sd, O.UNetConfig(), x.double(), c.double()).cpu()
+    y32 = ddpm.model(x, c).cpu()
+    ddpm.model.set_precision("fp16")
+    y16 = ddpm.model(x, c).cpu()
+    e32, e16 = rel_rms(y32, truth), rel_rms(y16, truth)
+    print(f"U-Net 64x1024 vs fp64: fp16 mode rel rms {e16:.2e} max {max_abs(y16, truth):.2e} | parity mode rel rms {e32:.2e}")
+    assert e32 < 1e-6 and 2e-5 < e16 < 3e-3
+
+    rng = lambda: r2dm_amd.setup_rng([0, 1], DEV)
+    s16 = ddpm.sample(batch_size=2, num_steps=48, progress=False, rng=rng()).clamp(-1, 1)
+    ddpm.model.set_precision("fp32")
+    s32 = ddpm.sample(batch_size=2, num_steps=48, progress=False, rng=rng()).clamp(-1, 1)
+    assert torch.equal(ddpm.model(x, c).cpu(), y32)
+    d = (s16 - s32).abs().flatten().double()
+    rms, q99, mx = d.pow(2).mean().sqrt().item(), torch.quantile(d[:: 4], 0.99).item(), d.max().item()
+    print(f"48-step DDPM sample, fp16 mode vs parity mode: rms {rms:.2e} q99 {q99:.2e} max {mx:.2e}")
+    assert torch.isfinite(s16).all() and rms < 2e-2 and q99 < 5e-2
+
+
+def test_mode_plumbing(tmp_path):
+    """setup_model(precision="fp16"), the deprecated alias, sample_and_save.py --precision fp16."""
+    import subprocess
+    import sys
+
+    import r2dm_amd
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = synthetic_ckpt(resolution=(64, 1024))
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=1, precision="fp16")
+    assert ddpm.model.precision == "fp16"
+    a = ddpm.sample(batch_size=1, num_steps=2, progress=False, rng=r2dm_amd.setup_rng([3], DEV))
+    path = tmp_path / "ck.pth"
+    torch.save(ck, path)
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "sample_and_save.py"), "--ckpt", str(path), "--output_dir", str(out), "--batch_size", "1",
+                        "--num_samples", "1", "--num_steps", "2", "--precision", "fp16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (out / "samples_0000000000.pth").exists() and torch.isfinite(a).all()

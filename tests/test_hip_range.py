@@ -1,0 +1,227 @@
+"""-m gpu: the default (22-bit split fp16 operand) kernels OFF the happy path -- VERDICT round 2, weak #2 / #3.
+
+Every other kernel test draws O(1) Gaussian operands.  Here: wide dynamic range, globally tiny weights (what the reference's
+zero-initialised tensors become after training: /root/reference/models/ops.py:9-11, efficient_unet.py:39,84,267), tiny
+activations (the split's absolute floor), large GroupNorm / AdaGN gains (the range guard must follow the data, not a
+worst-case estimate), and the guard's coverage where the fp32-MFMA kernel produces the operands of an fp16 consumer.
+
+The arithmetic under test: v = h + 2^-11 l with h = RNE_f16(v), l = RNE_f16(2^11 (v - h)); x w = xh wh + 2^-11 (xh wl + xl wh),
+the xl wl term (2^-22 relative) dropped.  Weights are scaled per layer by a power of two so that max|w| is in [2^9, 2^10)
+(exact; undone in the epilogue).  The representation has an ABSOLUTE floor: below |v| ~ 6e-5 h is an fp16 subnormal and below
+|v - h| ~ 3e-8 so is l, whose quantum 2^-24 then bounds the error of v at 2^-36 ~ 1.5e-11 -- relative to the layer's largest
+weight (after scaling: 2^-46) or, for activations, in absolute terms."""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_RES, max_abs, rnd, synthetic_ckpt
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")]
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import r2dm_oracle
+
+    return r2dm_oracle
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hipops
+
+    return hipops
+
+
+def rel_rms(a, ref):
+    return ((a.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def log_uniform(seed, lo, hi, *shape):
+    """sign * 10^U(lo, hi)"""
+    g = torch.Generator().manual_seed(seed)
+    mag = 10.0 ** (torch.rand(*shape, generator=g, dtype=torch.float64) * (hi - lo) + lo)
+    sign = torch.where(torch.rand(*shape, generator=g) < 0.5, -1.0, 1.0).double()
+    return (mag * sign).float()
+
+
+SHAPES = [(3, 64, 64, 16, 256), (3, 256, 256, 16, 256), (1, 256, 768, 8, 128), (1, 512, 512, 8, 128)]  # (ksize, cin, cout, h, w)
+
+
+@pytest.mark.parametrize("k,cin,cout,h,w", SHAPES)
+@pytest.mark.parametrize("wscale", [1.0, 1e-4, 1e-6, 1e-9])
+def test_tiny_weights_keep_fp32_class_relative_accuracy(O, H, k, cin, cout, h, w, wscale):
+    """A layer whose weights are globally tiny (a trained zero-initialised conv2 / out_proj): the relative error of the
+    split-operand kernels against fp64 must not depend on the weights' scale -- as it does not for an fp32 FMA chain.
+    Without the per-layer power-of-two scale of the packers the error at 1e-6 was ~1e-5 relative (l in the fp16 subnormals)."""
+    x = rnd(1, 2, cin, h, w)
+    wt = rnd(2, cout, cin, k, k) / math.sqrt(k * k * cin) * wscale
+    b = torch.zeros(cout)
+    ref = O.conv_ring(x.double(), wt.double(), b.double())
+    y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    f32 = O.conv_ring(x, wt, b)  # the reference's own fp32 arithmetic (torch CPU) as the yardstick
+    e_hip, e_f32 = rel_rms(y, ref), rel_rms(f32, ref)
+    print(f"k={k} {cin}->{cout} weights x{wscale:g}: rel rms hip {e_hip:.2e}, fp32 cpu {e_f32:.2e}")
+    assert e_hip < 4e-7 and e_hip < 2.0 * e_f32 + 5e-8
+
+
+@pytest.mark.parametrize("k,cin,cout,h,w", SHAPES[:3])
+def test_log_uniform_operands(O, H, k, cin, cout, h, w):
+    """Operand magnitudes log-uniform over eleven decades (1e-8 ... 1e3; weights 1e-8 ... 1, then 1/sqrt(K)): the output is
+    dominated by the largest products, and the error relative to the output's scale must be fp32-class (no cliff from the
+    small operands' subnormal pieces, no overflow of the large ones)."""
+    x = log_uniform(5, -8, 3, 2, cin, h, w)
+    wt = log_uniform(6, -8, 0, cout, cin, k, k) / math.sqrt(k * k * cin)
+    b = rnd(7, cout)
+    ref = O.conv_ring(x.double(), wt.double(), b.double())
+    y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    f32 = O.conv_ring(x, wt, b)
+    e_hip, e_f32 = rel_rms(y, ref), rel_rms(f32, ref)
+    print(f"k={k} {cin}->{cout} log-uniform: rel rms hip {e_hip:.2e}, fp32 cpu {e_f32:.2e}; max|y| {ref.abs().max():.1f}")
+    assert torch.isfinite(y).all() and e_hip < 4e-7 and e_hip < 2.0 * e_f32 + 5e-8
+
+
+@pytest.mark.parametrize("xscale", [1e-3, 1e-6])
+def test_tiny_activations_absolute_floor(O, H, xscale):
+    """Raw (not GroupNorm-normalised) activations that are globally tiny sit on the split's absolute floor: every element is
+    represented to ~1.5e-11 (2^-36), whatever its size.  With K = 9 x 64 products of |w| ~ 1/24 that is ~1.5e-11 on the
+    output -- fp32 keeps 6e-8 relative instead, so at |x| ~ 1e-6 the split is ~1e-5 relative: stated here and in DESIGN.md,
+    asserted as an absolute bound.  (GroupNorm inputs are renormalised and never get here; the network's raw inputs --
+    residual stream, attention output -- are O(1).)"""
+    cin, cout, h, w = 64, 64, 16, 256
+    x, wt, b = rnd(1, 2, cin, h, w) * xscale, rnd(2, cout, cin, 3, 3) / math.sqrt(9 * cin), torch.zeros(cout)
+    ref = O.conv_ring(x.double(), wt.double(), b.double())
+    y = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    err = (y.double() - ref).pow(2).mean().sqrt().item()
+    print(f"activations x{xscale:g}: abs rms error {err:.2e} (output rms {ref.pow(2).mean().sqrt():.2e})")
+    assert err < max(3e-11, 3e-7 * ref.pow(2).mean().sqrt().item())
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 256, 1024)])
+def test_attention_wide_dynamic_range(O, H, B, C, N):
+    """q, k small (flat softmax) and v log-uniform over eight decades: the fp16-pipe attention core against fp64."""
+    qk = rnd(11, B, 2 * C, N) * 0.05
+    v = log_uniform(12, -6, 2, B, C, N)
+    qkv = torch.cat([qk, v], 1).contiguous()
+    ref = O.attention_core(qkv.double(), 8) if hasattr(O, "attention_core") else None
+    if ref is None:
+        d = C // 8
+        q, kk, vv = (t.double().reshape(B, 8, d, N) for t in qkv.split(C, 1))
+        p = torch.softmax(torch.einsum("bhdn,bhdm->bhnm", q, kk) / math.sqrt(d), -1)
+        ref = torch.einsum("bhnm,bhdm->bhdn", p, vv).reshape(B, C, N)
+    y = H.attention(qkv.to(DEV), 8).cpu()
+    e = rel_rms(y, ref)
+    print(f"attention wide range: rel rms {e:.2e}")
+    assert torch.isfinite(y).all() and e < 5e-7
+
+
+# ---- the range guard follows the data -----------------------------------------------------------------------------------
+def _edited(ckpt, edit):
+    ck = dict(ckpt)
+    ck["ema_weights"] = dict(ck["ema_weights"])
+    edit(ck["ema_weights"])
+    return ck
+
+
+def test_large_adagn_scales_and_groupnorm_gains_run_in_the_default_mode(O):
+    """AdaGN scales ~ N(0, 3) (through the projection biases) and GroupNorm gains of +-100 on every channel -- far beyond
+    |gamma'| ~ 90, where the round-2 worst-case (Samuelson) bound refused the forward -- are ordinary numbers for the data:
+    |gamma' x_hat| stays below ~1e3.  The default mode must run them, agree with the fp64 oracle, and leave nothing pending."""
+    import r2dm_amd
+
+    g = torch.Generator().manual_seed(3)
+
+    def edit(w):
+        for k in list(w):
+            if k.endswith("norm2.proj.1.bias"):
+                C = w[k].numel() // 2
+                nb = w[k].clone()
+                nb[:C] = torch.randn(C, generator=g) * 3.0
+                w[k] = nb
+            if k.endswith("norm1.weight"):
+                w[k] = torch.where(torch.rand(w[k].shape, generator=g) < 0.5, -100.0, 100.0)
+
+    ck = _edited(synthetic_ckpt(), edit)
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=1)
+    x, c = rnd(95, 1, 2, 64, 1024).to(DEV), torch.tensor([0.5], device=DEV)
+    y = ddpm.model(x, c)  # (raises R2DMError if the guard trips)
+    sd = {k: v.double().to(DEV) for k, v in O.strip_prefix(ck["ema_weights"]).items()}
+    truth = O.unet_forward(sd, O.UNetConfig(), x.double(), c.double())
+    e = rel_rms(y.cpu(), truth.cpu())
+    print(f"gains +-100, AdaGN scales N(0,3): rel rms vs fp64 {e:.2e}, output rms {truth.pow(2).mean().sqrt().item():.3g}")
+    assert torch.isfinite(y).all() and e < 5e-6
+    ddpm.model.check_range()  # nothing pending
+
+
+def test_gains_that_really_leave_the_fp16_range_fail_loudly():
+    """A GroupNorm gain of 3e4 puts |gamma x_hat| ~ 1e5 > 65504 on the data themselves: the forward must fail (not return
+    saturated numbers), immediately and -- inside a sampling loop -- after the first step rather than after the last; the
+    bf16x3 mode (fp32 operand range) runs the same weights."""
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    def edit(w):
+        k = next(k for k in w if k.endswith("d_block1.residual_blocks.0.norm1.weight"))
+        w[k] = torch.full_like(w[k], 3.0e4)
+
+    ddpm, _, _ = r2dm_amd.setup_model(_edited(synthetic_ckpt(), edit), device=DEV, show_info=False, max_batch=2)
+    x, c = rnd(95, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
+    with pytest.raises(R2DMError, match="fp16 range"):
+        ddpm.model(x, c)
+    calls = []
+    fwd = ddpm.model.forward
+    ddpm.model.forward = lambda *a, **k: (calls.append(1), fwd(*a, **k))[1]
+    with pytest.raises(R2DMError, match="fp16 range"):
+        ddpm.sample(batch_size=2, num_steps=12, progress=False)
+    assert len(calls) == 1  # the early check: one denoiser call, not twelve
+    ddpm.model.forward = fwd
+    ddpm.model.set_precision("fp32-bf16x3")
+    assert torch.isfinite(ddpm.model(x, c)).all()
+    ddpm.model.check_range()
+
+
+def test_attention_operands_are_guarded_where_the_fp32_mfma_kernel_produces_them():
+    """at resolutions where proj_f16x2 does not apply (16x128: W/8 = 16 is not a multiple of 64) the
+    qkv projection runs on the fp32-MFMA kernel, which did not record max|qkv| -- the fp16 attention core ran unguarded.
+    A qkv bias of 1e5 must now make the forward fail; the bf16x3 mode runs it."""
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    def edit(w):
+        k = next(k for k in w if k.endswith("d_block4.self_attn_block.attn.in_proj_bias"))
+        w[k] = torch.full_like(w[k], 1.0e5)
+
+    ddpm, _, _ = r2dm_amd.setup_model(_edited(synthetic_ckpt(resolution=GOLDEN_RES), edit), device=DEV, show_info=False, max_batch=2)
+    x, c = rnd(98, 2, 2, *GOLDEN_RES).to(DEV), torch.zeros(2, device=DEV)
+    with pytest.raises(R2DMError, match="fp16 range"):
+        ddpm.model(x, c)
+    ddpm.model.set_precision("fp32-bf16x3")
+    assert torch.isfinite(ddpm.model(x, c)).all()
+
+
+def test_weight_flag_survives_blob_adoption():
+    """r2dm_bind_blob cleared the packer's 'weight not usable' flag, so a rank that ADOPTED a broadcast blob
+    ran silently where rank 0 raised.  A non-finite convolution weight must fail on the packing model and on the adopter."""
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    def edit(w):
+        k = next(k for k in w if k.endswith("d_block2.residual_blocks.1.conv1.weight"))
+        nw = w[k].clone()
+        nw[0, 0, 0, 0] = float("inf")
+        w[k] = nw
+
+    ck = _edited(synthetic_ckpt(), edit)  # (full size: the layer must be one the fp16 packings cover)
+    a, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    x, c = rnd(99, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
+    with pytest.raises(R2DMError, match="not finite"):
+        a.model(x, c)
+    blob = a.model.packed_weights(DEV).clone()
+    b, _, _ = r2dm_amd.setup_model(synthetic_ckpt(), device="cpu", show_info=False, max_batch=2)
+    b.to(DEV)
+    b.model.adopt_packed_weights(blob)
+    with pytest.raises(R2DMError, match="not finite"):
+        b.model(x, c)

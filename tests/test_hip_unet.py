@@ -321,8 +321,11 @@ def test_operand_split_modes_are_both_parity_modes():
     print(f"U-Net 64x1024 vs fp64: f16x2 mode rms {ra:.2e} max {max_abs(ya, truth):.2e} | bf16x3 mode rms {rb:.2e} max {max_abs(yb, truth):.2e}")
     assert ra < 4e-7 and rb < 5.5e-7 and max_abs(ya, truth) < 8e-6 and max_abs(yb, truth) < 8e-6  # ~2x measured
     assert ra < 1.1 * rb
+    with pytest.warns(DeprecationWarning):
+        net.set_precision("bf16x2")  # round 1's reduced mode: kept as a deprecated alias of the (faster, more accurate) default
+    assert net.precision == "fp32" and torch.equal(net(x.to(DEV), c.to(DEV)).cpu(), ya)
     with pytest.raises(ValueError):
-        net.set_precision("bf16x2")  # the reduced-precision mode of round 1 is gone: the parity path is the fast one
+        net.set_precision("int8")
 
 
 def test_repaint_kernels_replay_reference_ops():

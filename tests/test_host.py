@@ -92,6 +92,39 @@ def test_no_cpu_fallback():
         ddpm(torch.zeros(1, 2, *GOLDEN_RES))  # training loss is out of scope
 
 
+def test_refinenet_config_fails_like_the_reference():
+    """SURVEY.md section 8(f).4, last part: the reference's own setup_model cannot build architecture='refinenet'
+    (utils/inference.py:36 rebinds `in_channels` to an int, :54 calls sum() on it -> TypeError; verified by running the
+    reference on such a config in the dev container).  The drop-in raises the same error type with the same message head;
+    an unknown architecture raises the reference's ValueError("Unknown: ...") (utils/inference.py:60)."""
+    import copy
+
+    import r2dm_amd
+
+    ck = copy.deepcopy(synthetic_ckpt(resolution=GOLDEN_RES))
+    ck["cfg"]["model"]["architecture"] = "refinenet"
+    with pytest.raises(TypeError, match="'int' object is not iterable"):
+        r2dm_amd.setup_model(ck, device="cpu", show_info=False)
+    ck["cfg"]["model"]["architecture"] = "unet3"
+    with pytest.raises(ValueError, match="Unknown: unet3"):
+        r2dm_amd.setup_model(ck, device="cpu", show_info=False)
+
+
+def test_precision_names():
+    """`precision=` of setup_model / EfficientUNet.set_precision: two parity modes, the reduced fp16 bulk mode, round 1's
+    name as a deprecated alias; nothing else."""
+    import r2dm_amd
+
+    ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(resolution=GOLDEN_RES), device="cpu", show_info=False, precision="fp16")
+    net = ddpm.model
+    assert net.precision == "fp16" and sorted(net.PRECISIONS) == ["fp16", "fp32", "fp32-bf16x3"]
+    with pytest.warns(DeprecationWarning):
+        net.set_precision("bf16x2")
+    assert net.precision == "fp32"
+    with pytest.raises(ValueError):
+        net.set_precision("int8")
+
+
 def test_coefficient_tables_match_reference_schedule(golden):
     """Host-side schedule scalars are bit-identical to what the reference computes for batch 1 (golden 'schedule')."""
     from r2dm_amd import diffusion as D

@@ -77,18 +77,21 @@ size_t r2dm_workspace_bytes(const r2dm_handle* h, int32_t batch);
 int r2dm_unet_forward(r2dm_handle* h, const float* x, const float* cond, float* out, int32_t batch,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* -- operand split of the convolutions on the matrix pipe (all of them compute fp32 products to fp32 accuracy or
- *    better; there is no reduced-precision mode -- the reference's fp16 autocast bulk mode, sample_and_save.py:70,
- *    utils/option.py:49, has no counterpart here because the parity path is already the fast one):
- *      pieces = 2 (default): fp16 piece + 2^11-scaled fp16 residual (exact to 22 bits), 3 products, two accumulators:
- *                 conv_f16x2.hip for every 3x3 convolution, proj_f16x2.hip for every 1x1 convolution, the attention
- *                 core likewise.  An operand is either GroupNorm-normalised (bounded by |gamma'| sqrt(n) + |beta'|,
- *                 Samuelson, evaluated by the GroupNorm kernels) or its producer records max|output| (conv epilogues,
- *                 fir_up2); weight packing checks the weights;
- *      pieces = 3: three bf16 pieces / 6 products (conv_bf16x3.hip) for the 3x3 convolutions, the fp32-input MFMA for
- *                 the 1x1 convolutions and the attention core (fp32 operand range; the round-1 parity mode).
- *    fp16 tops out at 65504: with pieces = 2 r2dm_check_range reports a violation of any of these bounds.
- *    h == NULL sets the mode of the single-kernel entry r2dm_conv2d_ring. */
+/* -- arithmetic of the convolutions / attention core on the 16-bit matrix pipe (tensors and accumulation are fp32 in every mode):
+ *      pieces = 2 (default, parity mode): every fp32 operand v is split to 22 bits, v = h + 2^-11 l with h = RNE_f16(v),
+ *                 l = RNE_f16(2^11 (v - h)); a product is xh wh + 2^-11 (xh wl + xl wh) -- 3 MFMA products, the l x l term
+ *                 (2^-22 relative) dropped, two fp32 accumulators: conv_f16x2.hip (3x3), proj_f16x2.hip (1x1), attention.hip.
+ *                 fp32-class BY MEASUREMENT (error vs fp64 at or below an fp32 FMA chain's), not bit-exact fp32 operands.
+ *                 Operands pass through fp16 (|v| < 65504): weights are pre-scaled per layer by a power of two (max|w| into
+ *                 [2^9, 2^10); undone exactly in the epilogue); a GroupNorm-normalised operand is bounded from the DATA
+ *                 (|a| M + |d| with M >= max|x|: the square root of the largest statistics-slot energy, or the maximum the
+ *                 streaming statistics kernel recorded); a raw operand's producer records max|output| (conv epilogues, fir_up2);
+ *      pieces = 3 (parity mode, fp32 operand range): three bf16 pieces = exact 24-bit operands, 6 products (conv_bf16x3.hip)
+ *                 for the 3x3 convolutions, the fp32-input MFMA for the 1x1 convolutions and the attention core;
+ *      pieces = 1 (REDUCED precision, bulk sampling -- the reference's fp16 autocast mode, sample_and_save.py:70,
+ *                 utils/option.py:49): the kernels of pieces = 2 with the h piece alone: one fp16 product per MAC.
+ *    With pieces = 1 / 2 r2dm_check_range reports a violation of the fp16 operand range.
+ *    h == NULL sets the mode of the single-kernel entries r2dm_conv2d_ring / r2dm_attention. */
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
 
 /* Waits for `stream` and returns non-zero (r2dm_last_error explains) if, since the last call, a forward of `h` ran an
@@ -96,9 +99,9 @@ int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
  * calls this after every stand-alone forward and once at the end of a sampling loop. */
 int r2dm_check_range(r2dm_handle* h, void* stream);
 
-/* -- measurement aid (bench.py): when enabled, every convolution launch of a forward -- the split-bf16 3x3 kernels
- *    (conv_bf16x3_*), the fp32-MFMA kernel (conv_mfma_kernel: 1x1, in_conv) and the direct out_conv kernel, 64
- *    launches per forward -- is bracketed by hipEvents recorded on the caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed
+/* -- measurement aid (bench.py): when enabled, every convolution launch of a forward -- conv_f16x2_kernel (54 3x3 launches in
+ *    the default mode; conv_bf16x3_* with pieces = 3), proj_f16x2_kernel (8 1x1 launches; conv_mfma_kernel with pieces = 3) and
+ *    the two direct kernels (in_conv, out_conv), 64 launches per forward -- is bracketed by hipEvents recorded on the caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed
  *    ALGORITHMIC flops (2*B*Cout*Cin*k*k*H*W per launch) and the number of launches, then resets. */
 int r2dm_profile_enable(r2dm_handle* h, int32_t on);
 int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_t* launches);

@@ -81,11 +81,8 @@ struct ConvParams {
     // partial (sum, sum of squares) in fp64, one slot per (pixel tile, pixel wave): [B][stat_G][stat_slots][2]
     double* stat = nullptr;
     int stat_G = 0, stat_goff = 0, stat_cpg = 0, stat_slots = 0;
-    // ... and, beside every (sum, sum of squares) slot, the largest |output| that went into it: [B][stat_G][stat_slots] floats
-    // (or an upper bound of it: a wave writes the maximum over ALL its channels into each of its groups' slots).  The consuming
-    // GroupNorm turns it into the observed bound |a| max|x| + |d| on its output (gn_finalize) -- the fp16 range guard of the
-    // split-operand convolutions is data-driven, not a worst-case estimate.  nullptr: not recorded.
-    float* stat_max = nullptr;
+    // (the slots double as the fp16 range guard of the GroupNorm's consumers: every element of a slot is bounded by the
+    // square root of the slot's sum of squares -- gn_finalize, norm.hip: data-driven and free for the producer)
     // optional device scalar multiplied into the matrix product before the bias: the inverse of the power-of-two scale the
     // fp16 packers apply to a layer's weights (f16x2.h: max|w| is brought to [2^9, 2^10) so that tiny weights keep 22 bits)
     const float* wscale = nullptr;
@@ -134,11 +131,11 @@ struct GNParams {
     double* partial;     // scratch [B][G][splits][2]
     float2* aff;         // out [B][C]
     float* stats;        // optional out [B][G][2] (mean, rstd) for tests, may be nullptr
-    // optional device int[2]: [1] takes the running maximum (as float bits) of a bound on the normalised, affine-transformed
-    // tensor: the OBSERVED one, |a| max|x| + |d| per channel, when partial_max is given; else Samuelson's worst case
-    // |gamma'| sqrt(n) + |beta'| -- ALGO_F16X2 consumers need it below 65504 ([0]: weight flag of the packer)
+    // optional device int[2]: [1] takes the running maximum (as float bits) of a bound |a| M + |d| on the normalised, affine-
+    // transformed tensor, M >= max|x| taken from the DATA: the maximum gn_partial recorded (partial_max), or the square root of
+    // the largest slot energy (fused statistics) -- the fp16-operand consumers need it below 65504 ([0]: weight flag of the packer)
     int* range_flag = nullptr;
-    float* partial_max = nullptr;  // [B][G][splits]: largest |x| of every split (written by gn_partial / the convolution epilogues)
+    float* partial_max = nullptr;  // [B][G][splits]: largest |x| of every split (written by gn_partial), or nullptr
 };
 int gn_splits(int B, int groups, long group_elems);
 int conv_stat_slots(int H, int W);  // slots per (sample, group) a convolution's fused statistics occupy

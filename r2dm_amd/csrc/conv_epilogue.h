@@ -11,10 +11,9 @@ namespace r2dm {
 // Fused GroupNorm statistics, last step: the lanes of a wave hold 4 of the 8 channels (by half-wave) x 32 pixels of every
 // 8-channel block; reduce over the wave in fp64, merge the blocks of a group, one slot per (pixel tile, pixel wave) --
 // fixed summation order, every slot written exactly once per launch.
-// amax: this lane's largest |output| (over all the wave's channels); its wave maximum goes to stat_max beside every slot.
 template <int WPX, int MR>
 __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_s)[MR][4], double (&st_q)[MR][4], int b,
-                                               int th, int tw, int nTw, int co_u, int wave_px, int lane, float amax = 0.f) {
+                                               int th, int tw, int nTw, int co_u, int wave_px, int lane) {
     using gdouble = double __attribute__((address_space(1)))*;  // (global, not FLAT: flat stores also count on lgkmcnt)
     double bs[MR * 4], bq[MR * 4];
 #pragma unroll
@@ -32,7 +31,6 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
             bq[m * 4 + k8] = v[2 * k8 + 1];
         }
     }
-    const float wmax = p.stat_max ? wave_max_f32(amax) : 0.f;
     if (lane == 0) {
         // Slots per (sample, group): two halves of S = stat_slots / 2, each with one slot per (pixel tile, pixel
         // wave).  A wave whose 32*MR channels contain whole groups writes its sums to half 0 and zeros to half 1; a
@@ -66,12 +64,7 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
                         o[2 * S + 4] = 0.0;
                         o[2 * S + 5] = 0.0;
                     }
-                    if (p.stat_max) {
-                        float* om = p.stat_max + ((size_t)b * p.stat_G + g) * p.stat_slots + slot;
-                        om[0] = wmax;
-                        om[S] = 0.f;
-                        if (WPX == 2) om[2] = om[S + 2] = 0.f;
-                    }
+
                 }
             }
         } else {  // the wave's channels are one half of a group (bpg == 2 * R8)
@@ -86,7 +79,6 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
             gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + half * S + slot) * 2);
             o[0] = a;
             o[1] = q;
-            if (p.stat_max) p.stat_max[((size_t)b * p.stat_G + g) * p.stat_slots + half * S + slot] = wmax;
         }
     }
 }
@@ -97,9 +89,8 @@ __device__ __forceinline__ void epi_stat_write(const ConvParams& p, double (&st_
 // 1: squares); after the scatter lane L holds the wave total of v = (L >> 3) & 7.  Groups of 8 / 16 / 32 channels lie
 // inside the half (slot half 0, zeros to half 1); a 64-channel group takes the two halves of its wave in slot halves
 // 0 and 1, exactly as two 32-channel tiles would.  Fixed summation order, every slot written exactly once per launch.
-// amax: this lane's largest |output| within the half; its wave maximum goes to stat_max beside every slot of the half.
 __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double (&st_s)[4], double (&st_q)[4], int b, int th,
-                                                     int tw, int nTw, int co_half, int wave_px, int lane, float amax = 0.f) {
+                                                     int tw, int nTw, int co_half, int wave_px, int lane) {
     using gdouble = double __attribute__((address_space(1)))*;
     double v[8];
 #pragma unroll
@@ -114,7 +105,6 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
     if (bpg >= 4) wave_swap_add(t, t, false);   // + the other 32 lanes: blocks k8, k8 ^ 2
     const int k8 = (lane >> 4) & 3, kind = (lane >> 3) & 1;
     const int bin = bpg < 4 ? bpg : 4;  // blocks of a group inside this half
-    const float wmax = p.stat_max ? wave_max_f32(amax) : 0.f;
     if ((lane & 7) == 0 && (k8 & (bin - 1)) == 0) {
         const int S = p.stat_slots >> 1;
         const int slot = (th * nTw + tw) * 4 + wave_px;
@@ -123,12 +113,6 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
         gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2);
         o[2 * S * half + kind] = t;
         if (bpg < 8) o[2 * S + kind] = 0.0;
-        if (p.stat_max && kind == 0) {
-            using gfloat = float __attribute__((address_space(1)))*;
-            gfloat om = (gfloat)(p.stat_max + ((size_t)b * p.stat_G + g) * p.stat_slots + slot);
-            om[S * half] = wmax;
-            if (bpg < 8) om[S] = 0.f;
-        }
     }
 }
 
@@ -185,7 +169,6 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         double st_s[4], st_q[4];
-        float hmax = 0.f;  // largest |output| of this 32-channel half (p.stat_max)
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) st_s[k8] = st_q[k8] = 0.0;
 #pragma unroll
@@ -209,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
                 if (p.res) v = rv[q & 1][k8] + v;
                 if (p.scale) v *= sc;
                 (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]] = v;
-                if (p.range || p.stat_max) hmax = fmaxf(fmaxf(hmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                if (p.range) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (p.stat) {
                     const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
                     const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -218,8 +201,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
                 }
             }
         }
-        if (p.stat) epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, co_u + m * 32, wave_px, lane, hmax);
-        amax = fmaxf(amax, hmax);
+        if (p.stat) epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, co_u + m * 32, wave_px, lane);
     }
     if (p.range) {
         amax = wave_max_f32(amax);
@@ -296,7 +278,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     if (p.scale) v *= sc;
                     const bool live = px_ok[j] && co_u + cu + 4 * hi < p.Cout;
                     if (live) (yu + (long)cu * HW)[loff[j]] = v;
-                    if ((p.range || p.stat_max) && live) amax = fmaxf(amax, fabsf(v));
+                    if (p.range && live) amax = fmaxf(amax, fabsf(v));
                     if (p.stat) {
                         const double vm = live ? (double)v : 0.0;
                         st_s[m][r >> 2] += vm;
@@ -304,7 +286,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                 }
     }
-    if (p.stat) epi_stat_write<WPX, MR>(p, st_s, st_q, b, th, tw, nTw, co_u, wave_px, lane, amax);
+    if (p.stat) epi_stat_write<WPX, MR>(p, st_s, st_q, b, th, tw, nTw, co_u, wave_px, lane);
     if (p.range) {  // running max |output| (ConvParams::range), as in conv_epilogue_wide
         amax = wave_max_f32(amax);
         const int bits = __float_as_int(amax);

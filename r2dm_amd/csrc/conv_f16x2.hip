@@ -19,10 +19,11 @@
 // matrix-pipe operations per product.
 //
 // Range: fp16 tops out at 65504.  The kernel runs with MODE.FP16_OVFL set (conversions saturate instead of producing
-// inf), and the engine only routes convolutions here whose input is GroupNorm-normalised (PRO_AFFINE / PRO_AFFINE_SILU);
-// gn_finalize bounds |a x + d| <= |gamma'| sqrt(n) + |beta'| per channel (Samuelson) and raises the engine's range flag
-// if that could exceed the fp16 range, in which case the forward fails loudly (engine.hip).  Weights are checked when
-// they are packed.
+// inf), and the engine only routes convolutions here whose input range is guarded from the data: GroupNorm-normalised
+// inputs by gn_finalize's bound |a| M + |d| (M >= max|x| from the statistics slots, norm.hip), raw inputs by their producer's
+// recorded max|output|; a violation raises the engine's range flag and the forward fails loudly (engine.hip).  Weights are
+// scaled per layer by a power of two when they are packed (max|w| into [2^9, 2^10): tiny weights keep their 22 bits, none can
+// leave the range); the inverse scale (ConvParams::wscale) multiplies the matrix product in the epilogue -- exact.
 //
 // Who does what (as in the round-2 timeline analysis: beside a running MFMA stream every other instruction costs issue
 // slots in whichever wave it sits, so the multiplying waves carry nothing else):
@@ -589,7 +590,6 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
     f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
     float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
-    float cmx = 0.f;                  // ... and its largest |output| (p.stat_max)
     float amax_e = 0.f;
     int pe_b = 0, pe_th = 0, pe_tw = 0, pe_cot = 0;
     bool pending = false;
@@ -621,27 +621,24 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             for (int j = 0; j < 4; ++j) dst[k8 * 256 + (j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
     };
     // bias, residual, scale, store, statistics of one turned quarter (t[k8]: 4 consecutive pixels of channel 8 k8 + lane / 8)
-    auto quarter = [&](auto QD, const f32x4 (&t)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4], float& pm) __attribute__((always_inline)) {
+    auto quarter = [&](auto QD, const f32x4 (&t)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
         const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)(cot * CO_T) * HW);
-        float qm = 0.f;
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             f32x4 v = t[k8] * wsc + bias_e[m * 4 + k8];
             if (p.res) v = rv_e[k8] + v;
             v *= sc_blk;  // (1.0f without p.scale: exact)
             (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
-            if (p.range || p.stat_max) qm = fmaxf(fmaxf(qm, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);
             pq[k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
         }
-        pm = qm;
-        if (p.range) amax_e = fmaxf(amax_e, qm);
     };
     auto half_stats = [&](auto M, const float (&s0)[4], const float (&q0)[4], const float (&s1)[4], const float (&q1)[4], int b, int th,
-                          int tw, int cot, int ln, float hmax) __attribute__((always_inline)) {
+                          int tw, int cot, int ln) __attribute__((always_inline)) {
         if (!p.stat) return;
         double st_s[4], st_q[4];
 #pragma unroll
@@ -649,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             st_s[k8] = (double)s0[k8] + (double)s1[k8];
             st_q[k8] = (double)q0[k8] + (double)q1[k8];
         }
-        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * CO_T + decltype(M)::value * 32, wave, ln, hmax);
+        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * CO_T + decltype(M)::value * 32, wave, ln);
     };
     auto range_flush = [&](int ln) __attribute__((always_inline)) {
         if (!p.range) return;
@@ -665,17 +662,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         f32x4 t[4];
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + (S - 1) * 1024 + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
-        float ps[4], pq[4], pm;
-        quarter(SS, t, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq, pm);
+        float ps[4], pq[4];
+        quarter(SS, t, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq);
         if (S < 3) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
-        if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln, fmaxf(cmx, pm));
+        if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
         if (S == 2) {
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) { cs[k8] = ps[k8]; cq[k8] = pq[k8]; }
-            cmx = pm;
         }
         if (S == 3) {
-            half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln, fmaxf(cmx, pm));
+            half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
             range_flush(ln);
             pending = false;
         }
@@ -727,7 +723,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     turn_write(ic<1>{}, dump, ln);
                     turn_write(ic<2>{}, dump + 1024, ln);
                     turn_write(ic<3>{}, dump + 2048, ln);
-                    quarter(ic<0>{}, t, e_b, e_th, e_tw, e_cot, ln, cs, cq, cmx);
+                    quarter(ic<0>{}, t, e_b, e_th, e_tw, e_cot, ln, cs, cq);
                     res_request(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
                 }
                 pe_b = e_b; pe_th = e_th; pe_tw = e_tw; pe_cot = e_cot;

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
     constexpr int EPI_N = (C::MR * C::NR * 16 <= 64) ? C::NR : (C::NR / 2 > 0 ? C::NR / 2 : 1);
     double st_s[C::MR][4], st_q[C::MR][4];  // fused GroupNorm statistics (fp64: E[x^2]-E[x]^2 must not see fp32
                                             // roundoff), per 8-channel block of this wave
-    float amax = 0.f;                       // largest |output| of this lane (p.range / p.stat_max)
+    float amax = 0.f;                       // largest |output| of this lane (p.range)
 #pragma unroll
     for (int m = 0; m < C::MR; ++m)
 #pragma unroll
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
                     if (p.scale) v *= sc;
                     const bool live = px_ok[j] && co_u + cu + 4 * hi < p.Cout;
                     if (live) (yu + (long)cu * HW)[loff[j]] = v;
-                    if ((p.range || p.stat_max) && live) amax = fmaxf(amax, fabsf(v));
+                    if (p.range && live) amax = fmaxf(amax, fabsf(v));
                     if (p.stat) {
                         const double vm = live ? (double)v : 0.0;
                         st_s[m][r >> 2] += vm;
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
                     }
                 }
     }
-    if (p.range || p.stat_max) amax = wave_max_f32(amax);
     if (p.range) {  // running max |output| (ConvParams::range): the consumer runs on the fp16 matrix pipe
+        amax = wave_max_f32(amax);
         const int bits = __float_as_int(amax);  // positive floats order like their bit patterns
         if (lane == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
     }
@@ -473,12 +473,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvParams p)
                         o[S2 + 4] = 0.0;
                         o[S2 + 5] = 0.0;
                     }
-                    if (p.stat_max) {  // the wave's largest |output| beside each of its groups' slots (conv_epilogue.h)
-                        float* om = p.stat_max + ((size_t)b * p.stat_G + g) * p.stat_slots + slot;
-                        om[0] = amax;
-                        om[S2 >> 1] = 0.f;
-                        if (WPX == 2) om[2] = om[(S2 >> 1) + 2] = 0.f;
-                    }
+
                 }
             }
         }

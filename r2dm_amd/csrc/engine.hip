@@ -396,7 +396,6 @@ struct Ctx {
     // Sink from its epilogue; the GroupNorm then only runs the finalize kernel (no extra pass over the tensor).
     struct Sink {
         double* p = nullptr;
-        float* pm = nullptr;            // largest |output| beside every slot (ConvParams::stat_max): the observed range bound
         int C = 0, cpg = 0, slots = 0;  // C: channels of the normalised (possibly concatenated) tensor
         bool incomplete = false;        // a producer could not emit its share: the consumer runs the streaming pass instead
         explicit operator bool() const { return p != nullptr && !incomplete; }
@@ -411,8 +410,7 @@ struct Ctx {
         k.C = C_total;
         k.cpg = cpg;
         k.slots = conv_stat_slots(H, W);
-        k.p = (double*)ar->alloc((size_t)B * G * k.slots * (2 * sizeof(double) + sizeof(float)));
-        k.pm = (float*)(k.p + (size_t)B * G * k.slots * 2);
+        k.p = (double*)ar->alloc((size_t)B * G * k.slots * 2 * sizeof(double));
         return k;
     }
     void drop_sink(Sink& k) {
@@ -429,7 +427,7 @@ struct Ctx {
         if (!dry()) {
             GNParams g{Src{}, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows, k.p, aff,
                        nullptr};
-            g.partial_max = k.pm;
+            // (range guard of the fp16 consumers: the slot energies bound max|x| -- norm.hip; no separate maximum is recorded)
             if (h->f16_path()) g.range_flag = (int*)blob(h->range_flag);  // (only the fp16 operand paths have a range to guard)
             note(launch_group_norm_finalize(g, k.C, k.slots, st), "group_norm_finalize");
         }
@@ -508,7 +506,6 @@ struct Ctx {
             if (track_out && h->f16_path() && p.algo != ALGO_DIRECT) p.range = (int*)blob(h->range_flag);
             if (fused_stats) {
                 p.stat = sink->p;
-                p.stat_max = sink->pm;
                 p.stat_G = h->cfg.gn_num_groups;
                 p.stat_goff = goff;
                 p.stat_cpg = sink->cpg;
@@ -830,8 +827,8 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
         return fail(2, "a convolution weight is not finite (the fp16 packings scale every layer into the fp16 range, so only inf / nan "
                        "get here); the weights are not usable");
     if (!(bound < 65504.f))
-        return fail(2, "an input of the fp16-operand convolution path is outside the fp16 range (65504): largest observed bound "
-                       "(GroupNorm outputs: |a| max|x| + |d| from the producers' recorded maxima; raw inputs: max|x|) = %.3g; results of "
+        return fail(2, "an input of the fp16-operand convolution path may be outside the fp16 range (65504): largest data-driven bound "
+                       "(GroupNorm outputs: |a| M + |d|, M >= max|x| from the statistics slots; raw inputs: recorded max|x|) = %.3g; results of "
                        "this forward are not valid; select the bf16x3 split with r2dm_set_conv_pieces(h, 3)", (double)bound);
     return 0;
 }

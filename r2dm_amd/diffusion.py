@@ -306,6 +306,44 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
             hit = cache[key] = (cond, coef, mode_id)
         return hit
 
+    def _table_rows(self, num_steps: int, batch_size: int, mode: str, ddim_eta: float, dev):
+        """``row(i) -> (cond (B,), coef (B, 8))`` and ``mode_id`` for a ``sample`` call.  A cached table is indexed; a new one is
+        built ROW BY ROW while the loop runs: each row is ~0.3 ms of host work (about thirty 1-element torch ops), 80 ms for 256
+        steps -- with the whole table built up front that was 4.5 % of a cold 256-step call with the GPU idle (round 3:
+        scripts/step_times.py, profiles/r03_step_times.txt), whereas one row per step hides under the ~6 ms the GPU needs per
+        step.  Rows travel through pinned host memory (an asynchronous copy on the sampling stream: the host never waits for the
+        GPU) into the device table, which enters the cache when its last row is in."""
+        dev = torch.device(dev)
+        key = (num_steps, batch_size, mode, float(ddim_eta), str(dev), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high)
+        cache = self.__dict__.setdefault("_tables", {})
+        hit = cache.get(key)
+        if hit is not None:
+            cond, coef, mode_id = hit
+            return (lambda i: (cond[i], coef[i])), mode_id
+        if mode not in ("ddpm", "ddim"):
+            raise ValueError(f"invalid mode {mode}")
+        mode_id = _M_CT_DDPM if mode == "ddpm" else _M_CT_DDIM
+        steps = torch.linspace(1.0, 0.0, num_steps + 1)
+        pin = dev.type == "cuda"
+        h_cond = torch.empty(num_steps, batch_size, pin_memory=pin)
+        h_coef = torch.empty(num_steps, batch_size, _NCOEF, pin_memory=pin)
+        cond = torch.empty(num_steps, batch_size, device=dev)
+        coef = torch.empty(num_steps, batch_size, _NCOEF, device=dev)
+
+        def row(i):
+            c, k, _ = self._coefficients(steps[i:i + 1], steps[i + 1:i + 2], mode, ddim_eta)
+            h_cond[i] = c
+            h_coef[i] = k[0]
+            cond[i].copy_(h_cond[i], non_blocking=True)
+            coef[i].copy_(h_coef[i], non_blocking=True)
+            if i == num_steps - 1:
+                if len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                cache[key] = (cond, coef, mode_id)
+            return cond[i], coef[i]
+
+        return row, mode_id
+
     @torch.inference_mode()
     def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
@@ -326,14 +364,15 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=dev)
         if return_all:
             out = [x]
-        cond, coef, mode_id = self._sample_tables(num_steps, batch_size, mode, ddim_eta, dev)
+        row, mode_id = self._table_rows(num_steps, batch_size, mode, ddim_eta, dev)
         with _range_guard(self.model):
             for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-                prediction = self.model(x, cond[i])
+                cond_i, coef_i = row(i)
+                prediction = self.model(x, cond_i)
                 if i == 0 and num_steps > 8:
                     _early_range_check(self.model)  # a checkpoint the fp16 operand path cannot run fails now, not after the loop
                 noise = self.randn_like(x, rng=rng)
-                x = self._posterior(x, prediction, noise, coef[i], mode_id)
+                x = self._posterior(x, prediction, noise, coef_i, mode_id)
                 if return_all:
                     out.append(x)
         return torch.stack(out) if return_all else x

@@ -107,9 +107,9 @@ def test_attention_one_product(H):
 def test_unet_and_sampler_tolerance_class(O):
     """The stated tolerance class of the mode, measured at 64x1024 (synthetic untrained network, the hardest case: its gains are
     higher than a trained one's):
-      U-Net forward vs the fp64 oracle      rel rms < 3e-3   (parity mode: ~1e-7; an fp16-autocast torch forward: same class)
-      48-step DDPM final sample vs the parity mode on the same noise   rms < 2e-2 on a [-1, 1] range image, and the
-      clamped samples agree in 99 % of the pixels to 5e-2.
+      U-Net forward vs the fp64 oracle      rel rms < 3e-3, measured 1.5e-3   (parity mode: 1.3e-6; an fp16-autocast torch forward: same class)
+      48-step DDPM final sample vs the parity mode on the same noise, [-1, 1] range image: rms < 1e-3, 99th percentile
+      < 4e-3, max < 5e-2 (measured 2.4e-4 / 9.9e-4 / 7.1e-3; the parity mode itself: max 7e-6 against the fp64 oracle).
     Switching back restores the parity mode bit for bit; the mode is never the default."""
     import r2dm_amd
 
@@ -124,7 +124,7 @@ def test_unet_and_sampler_tolerance_class(O):
     y16 = ddpm.model(x, c).cpu()
     e32, e16 = rel_rms(y32, truth), rel_rms(y16, truth)
     print(f"U-Net 64x1024 vs fp64: fp16 mode rel rms {e16:.2e} max {max_abs(y16, truth):.2e} | parity mode rel rms {e32:.2e}")
-    assert e32 < 1e-6 and 2e-5 < e16 < 3e-3
+    assert e32 < 3e-6 and 2e-4 < e16 < 3e-3
 
     rng = lambda: r2dm_amd.setup_rng([0, 1], DEV)
     s16 = ddpm.sample(batch_size=2, num_steps=48, progress=False, rng=rng()).clamp(-1, 1)
@@ -134,7 +134,7 @@ def test_unet_and_sampler_tolerance_class(O):
     d = (s16 - s32).abs().flatten().double()
     rms, q99, mx = d.pow(2).mean().sqrt().item(), torch.quantile(d[:: 4], 0.99).item(), d.max().item()
     print(f"48-step DDPM sample, fp16 mode vs parity mode: rms {rms:.2e} q99 {q99:.2e} max {mx:.2e}")
-    assert torch.isfinite(s16).all() and rms < 2e-2 and q99 < 5e-2
+    assert torch.isfinite(s16).all() and rms < 1e-3 and q99 < 4e-3 and mx < 5e-2  # measured 2.4e-4 / 9.9e-4 / 7.1e-3
 
 
 def test_mode_plumbing(tmp_path):

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(d + 'bench_kt_kernel_stats.csv')))
 jk = json.load(open(d + 'bench_kt.json'))
 nsteps = sum(int(r['Calls']) for r in rows if 'posterior_kernel' in r['Name'])  # one posterior update per reverse step
 out.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-torch-baseline   (1x MI355X, batch 8; {nsteps} reverse steps in the trace: "
-           f"~1 s clock pre-warm + {jk['warmup']} warm-up + {jk['steps']} timed + {min(jk['steps'], 4)} profiled)\n")
+           f"clock pre-warm + {jk['warmup']} warm-up + {jk['steps']} timed + {min(jk['steps'], 4)} profiled)\n")
 out.append("%-86s %7s %9s %11s %10s %7s" % ("kernel", "calls", "per step", "total_ms", "avg_us", "pct"))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:22]:
@@ -69,7 +69,7 @@ out.append("=> HBM-side traffic %.0f-%.0f MB per launch: no wasted re-reads (hal
 
 # ---- memory-bound kernels: achieved HBM GB/s from the kernel trace (config 1 shapes, batch 8: bytes per step by construction)
 MB = {  # kernel substring -> (algorithmic MB per step, what)
-    'fir_down2_kernel': (587.2, "3 launches: 128ch@64x1024, 256ch@32x512, 512ch@16x256 read + quarter-size write"),
+    'fir_down2': (587.2, "3 launches: 128ch@64x1024, 256ch@32x512, 512ch@16x256 read + quarter-size write"),
     'fir_up2_kernel': (293.6, "3 launches: 256ch@8x128, 128ch@16x256, 64ch@32x512 read + 4x write"),
     'gn_partial_kernel': (117.4, "3 launches (statistics of the three FIR-down outputs): one read"),
     'posterior_kernel': (16.8, "1 launch: x_t, prediction, noise read + x_s written, 8x2x64x1024 fp32 each"),

@@ -217,6 +217,45 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
         assert torch.equal(two["samples"], one["samples"])
 
 
+_RCCL_SELFTEST = r"""
+import os, sys, torch
+import torch.distributed as td
+sys.path.insert(0, sys.argv[1])
+import r2dm_amd
+from r2dm_amd import synthetic
+from r2dm_amd.distributed import sample_sharded
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+td.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1, device_id=dev)  # "nccl" IS RCCL on ROCm
+res = (16, 128)
+a, _, _ = r2dm_amd.setup_model(synthetic.synthetic_checkpoint(seed=0, resolution=res), device=dev, show_info=False, max_batch=2)
+b, _, _ = r2dm_amd.setup_model(synthetic.synthetic_checkpoint(seed=1, resolution=res), device=dev, show_info=False, max_batch=2)
+wire = torch.empty_like(a.model.packed_weights(dev))
+wire.copy_(a.model.packed_weights(dev))
+td.broadcast(wire, src=0)                      # the blob through an RCCL broadcast kernel
+b.model.adopt_packed_weights(wire)
+x = torch.randn(2, 2, *res, device=dev); c = torch.tensor([0.3, -2.0], device=dev)
+assert torch.equal(a.model(x, c), b.model(x, c))
+t = torch.ones(4, device=dev); td.all_reduce(t); torch.cuda.synchronize(); assert t.sum().item() == 4.0
+out, mine = sample_sharded(lambda seeds: a.sample(batch_size=len(seeds), num_steps=2, progress=False, rng=r2dm_amd.setup_rng(seeds, dev)), [5, 6])
+assert mine == [5, 6] and out.shape[0] == 2
+td.barrier(); td.destroy_process_group()
+print("RCCL_SELFTEST_OK", td.is_nccl_available())
+"""
+
+
+def test_rccl_backend_executes_on_this_gpu():
+    """The multi-GPU path uses torch.distributed's "nccl" backend (= RCCL on ROCm) for one broadcast of the packed weight blob
+    (r2dm_amd/distributed.py; /root/reference/sample_and_save.py:25-46 re-reads the checkpoint on every rank instead).  The GPU
+    boxes this suite runs on have ONE device, so the N-rank form cannot run here (gloo world-size-2: tests/test_distributed_cpu.py,
+    test_two_rank_bench_on_one_gpu...); this test at least executes the RCCL communicator set-up, a broadcast of the real blob, an
+    all-reduce and a barrier on the hardware with a one-rank group, and checks that a model adopting the broadcast blob
+    reproduces the packing model bit for bit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SELFTEST, ROOT, str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_SELFTEST_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 @pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
 def test_forwards_next_to_a_second_process(tmp_path):
     """Round 2 saw wrong forwards whenever a second process computed on the same GPU; round 3 traced it to ONE kernel (the old

@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--prewarm-s", type=float, default=2.0, help="minimum seconds of untimed sampling before the warm-up steps; continues "
                     "(up to 4x as long) until two consecutive 0.5 s windows agree within 1 %% in shader clock and board power")
     ap.add_argument("--no-exact-baseline", action="store_true", help="skip the fp32-bf16x3 (exact 24-bit operand split) timing")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[2] and configs[4] that ride on the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "fp32-bf16x3", "fp16"], default="fp32",
@@ -404,6 +405,34 @@ def main():
                                                     "product (conv_bf16x3.hip), fp32-input MFMA for 1x1 convolutions and attention"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ck, cf)
+        if world == 1 and args.config == 1 and args.precision == "fp32" and args.batch is None and not args.no_other_configs:
+            # BASELINE configs[2] and configs[4] (per-GPU shard) beside the headline, same process and board state: one timed
+            # sample() call each after a 1 s pre-warm (their full lines incl. baselines: `--config 2` / `--config 4`)
+            del ddpm
+            torch.cuda.empty_cache()
+            others = {}
+            for ci, osteps in ((2, 32), (4, 8)):
+                oc = CONFIGS[ci]
+                ock = synthetic.synthetic_checkpoint(seed=0, resolution=oc["res"])
+                om, _, _ = r2dm_amd.setup_model(ock, device=dev, show_info=False, max_batch=oc["batch"], precision=args.precision)
+                oseeds = list(range(oc["batch"]))
+                orun = lambda n: om.sample(batch_size=oc["batch"], num_steps=n, progress=False, mode=oc["mode"], rng=r2dm_amd.setup_rng(oseeds, dev))
+                t_pw = time.perf_counter()
+                while time.perf_counter() - t_pw < 1.0:
+                    orun(4)
+                    torch.cuda.synchronize()
+                orun(osteps)  # (same step count as the timed call: its schedule table is then cached, as for any repeated call)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                oo = orun(osteps)
+                torch.cuda.synchronize()
+                odt = time.perf_counter() - t1
+                assert torch.isfinite(oo).all()
+                others["configs[%d]" % ci] = {"workload": oc["workload"], "metric": oc["metric"], "value": oc["batch"] / (odt / osteps * oc["sampler_steps"]),
+                                              "unit": "images/s per GPU", "ms_per_step": odt / osteps * 1e3, "steps": osteps}
+                del om
+                torch.cuda.empty_cache()
+            line["other_configs"] = others
         print(json.dumps(line))
     if dist:
         td.destroy_process_group()

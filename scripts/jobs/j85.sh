@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/j85; mkdir -p $O
 cd /tmp
-A="--no-cpu-baseline --no-torch-baseline --no-exact-baseline"
+A="--no-cpu-baseline --no-torch-baseline --no-exact-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench_kt -- python $R/bench.py $A --prewarm-s 0.5 > $O/bench_kt.json 2> $O/bench_kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o bench_fetch -- python $R/bench.py $A --steps 4 --warmup 1 --prewarm-s 0.1 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o bench_write -- python $R/bench.py $A --steps 4 --warmup 1 --prewarm-s 0.1 > $O/pmc_write.json 2> $O/pmc_write.err

@@ -199,7 +199,7 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     DESIGN.md section 6): the failure belonged to the old LDS-tiled out_conv kernel, disappeared with the commit that replaced it
     (1c7a0dc) and does not occur with any kernel of the current library -- 0 of 700 forwards at batch 2 / 8, both operand splits."""
     env = dict(os.environ, R2DM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-torch-baseline", "--no-exact-baseline", "--prewarm-s", "0.5"]
+    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-torch-baseline", "--no-exact-baseline", "--no-other-configs", "--prewarm-s", "0.5"]
     d2 = tmp_path / "two"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump-samples", str(d2)] + common,

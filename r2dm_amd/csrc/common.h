@@ -89,6 +89,9 @@ struct ConvParams {
     // optional: range[1] takes the running maximum of |output| as float bits -- the engine asks for it when the consumer runs on
     // the fp16 matrix pipe with no GroupNorm in between (a down-sampling convolution; the attention core behind the qkv projection)
     int* range = nullptr;
+    // walk the launch's tiles in descending order (conv_f16x2.hip): consecutive layers then alternate direction, so a layer starts on the
+    // part of its input that its producer wrote LAST -- the part most likely still in the 256 MB Infinity Cache (level-1 tensors are 134 MB)
+    int reverse = 0;
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
 int conv_pick_algo(int Cin, int Cout, int taps);  // env R2DM_CONV_ALGO=f32 forces ALGO_F32 everywhere

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     // tile `it` of this block -> output channel tile, sample, tile row / column (all wave-uniform: scalar ALU, F2Div)
     auto udiv = [&](unsigned x, int d, unsigned m) __attribute__((always_inline)) { return d == 1 ? x : __umulhi(x, m); };
     auto decode = [&](int it, int& cot, int& b, int& th, int& tw) __attribute__((always_inline)) {
-        const unsigned L = (unsigned)__builtin_amdgcn_readfirstlane(xcd_remap((int)blockIdx.x + it * G, total_tiles));
+        unsigned L = (unsigned)__builtin_amdgcn_readfirstlane(xcd_remap((int)blockIdx.x + it * G, total_tiles));
+        if (p.reverse) L = (unsigned)total_tiles - 1u - L;
         const unsigned t1 = udiv(L, nCoT, dv.co), t2 = udiv(t1, nTw, dv.tw), t3 = udiv(t2, nTh, dv.th);
         cot = (int)(L - t1 * (unsigned)nCoT);
         tw = (int)(t1 - t2 * (unsigned)nTw);

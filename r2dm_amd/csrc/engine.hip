@@ -372,6 +372,7 @@ struct Ctx {
     double* gn_partial;
     hipError_t err = hipSuccess;
     const char* where = "";
+    int f2_launches = 0;  // conv_f16x2 launches of this forward so far (odd ones walk their tiles backwards: ConvParams::reverse)
 
     bool dry() const { return ar->dry; }
     void note(hipError_t e, const char* w) {
@@ -489,6 +490,8 @@ struct Ctx {
             // the fp16 split where the input's range is guarded: GroupNorm-normalised (gn_finalize's bound) or tracked by its
             // producer (fir_up2's running maximum)
             if (L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded)) {
+                static const int rev_mode = getenv("R2DM_TILE_ORDER") ? atoi(getenv("R2DM_TILE_ORDER")) : 1;  // 0: always ascending (experiments)
+                p.reverse = rev_mode ? (f2_launches++ & 1) : 0;
                 p.algo = ALGO_F16X2;
                 p.w = blob(L.w_f2);
                 p.wscale = blob(L.ws_f2) + 1;

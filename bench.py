@@ -103,9 +103,25 @@ def torch_rocm_baseline(ck, cf, B, dev):
         O.sample_continuous(net, shape, n, rng=rng, mode=cf["mode"], device=dev)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    return {"value": B / (dt / n * cf["sampler_steps"]), "unit": "images/s", "ms_per_step": dt / n * 1e3,
-            "kind": "oracle via PyTorch-ROCm (torch %s: MIOpen / rocBLAS, fp32, eager)" % torch.__version__,
-            "sample": f"sample(batch={B}, {n} {cf['mode'].upper()} steps after 1 warm-up step), scaled to the {cf['sampler_steps']}-step sampler"}
+    out = {"value": B / (dt / n * cf["sampler_steps"]), "unit": "images/s", "ms_per_step": dt / n * 1e3,
+           "kind": "oracle via PyTorch-ROCm (torch %s: MIOpen / rocBLAS, fp32, eager)" % torch.__version__,
+           "sample": f"sample(batch={B}, {n} {cf['mode'].upper()} steps after 1 warm-up step), scaled to the {cf['sampler_steps']}-step sampler"}
+    # ... and the way the reference's BULK sampler runs it: the denoiser under fp16 autocast (sample_and_save.py:70) -- the counterpart of
+    # `--precision fp16` here, reported beside the fp32 figure (vs_baseline uses the fp32 one: same arithmetic class as the headline)
+    try:
+        anet = lambda x, c: torch.autocast("cuda", dtype=torch.float16)(net)(x, c).float()
+        with torch.inference_mode():
+            O.sample_continuous(anet, shape, 1, rng=rng, mode=cf["mode"], device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            O.sample_continuous(anet, shape, n, rng=rng, mode=cf["mode"], device=dev)
+            torch.cuda.synchronize()
+            dta = time.perf_counter() - t0
+        out["fp16_autocast"] = {"value": B / (dta / n * cf["sampler_steps"]), "unit": "images/s", "ms_per_step": dta / n * 1e3,
+                                "kind": "the same oracle under torch.autocast(fp16), eager"}
+    except Exception as e:  # (an autocast path MIOpen cannot serve must not take the line down)
+        out["fp16_autocast"] = {"error": repr(e)[:200]}
+    return out
 
 
 class BoardSampler:
@@ -388,7 +404,13 @@ def main():
             # north_star: ">= N x the reference single-GPU PyTorch sampler" -- BASELINE.md has no published number for this
             # metric, so the baseline is the one measured beside it in this run
             line["vs_baseline"] = value / tb["value"]
-            line["vs_baseline_definition"] = "value / torch_rocm_baseline.value (the reference's sampler as stock PyTorch-ROCm runs it on this GPU, same run)"
+            line["vs_baseline_definition"] = "value / torch_rocm_baseline.value (the reference's sampler as stock PyTorch-ROCm runs it on this GPU, fp32, same run)"
+            ac = tb.get("fp16_autocast", {})
+            if "value" in ac:
+                ac["speedup"] = value / ac["value"]
+                if args.precision == "fp16":  # the reduced mode is compared with the reference's reduced mode
+                    line["vs_baseline"] = value / ac["value"]
+                    line["vs_baseline_definition"] = "value / torch_rocm_baseline.fp16_autocast.value (the reference's fp16-autocast bulk mode on this GPU, same run)"
         if world == 1 and not args.no_exact_baseline and args.precision == "fp32":
             ddpm.model.set_precision("fp32-bf16x3")
             prewarm(1.0)

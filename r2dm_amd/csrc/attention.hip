@@ -304,10 +304,53 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
         }
 }
 
+// ---- any head size up to 128, any token count: plain fp32 on the vector ALU ------------------------------------------------
+// The matrix-pipe kernels above cover what the LiDAR checkpoints use (head size 32 / 64, tokens a multiple of 32).  Other
+// geometries the reference accepts (base_channels = 96 -> head size 96; a 16 x 64 image -> 16 tokens, ...) used to be refused;
+// they are rare and small, so they get a simple kernel: one thread per query, the keys in order, online softmax, every K / V
+// element a wave-uniform (broadcast) load.  fp32 FMA chains = the reference's math path.
+template <int DMAX>
+__global__ __launch_bounds__(64) void attention_generic_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int D, int N,
+                                                               float scale) {
+    const int n = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const bool active = n < N;
+    const float* qp = qkv + ((long)b * 3 * C + (long)h * D) * N;
+    const float* kp = qp + (long)C * N;
+    const float* vp = kp + (long)C * N;
+    float q[DMAX], o[DMAX];
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e) {
+        q[e] = (e < D && active) ? qp[(long)e * N + n] * scale : 0.f;
+        o[e] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < DMAX; ++e)
+            if (e < D) s = fmaf(q[e], kp[(long)e * N + j], s);
+        const float m_new = fmaxf(m, s);
+        const float a = __expf(m - m_new), p = __expf(s - m_new);
+        l = l * a + p;
+        m = m_new;
+#pragma unroll
+        for (int e = 0; e < DMAX; ++e)
+            if (e < D) o[e] = fmaf(p, vp[(long)e * N + j], o[e] * a);
+    }
+    if (!active) return;
+    const float inv = 1.0f / l;
+    float* op = out + ((long)b * C + (long)h * D) * N + n;
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e)
+        if (e < D) op[(long)e * N] = o[e] * inv;
+}
+
+static bool attention_fast_path(int d, int N) { return (d == 32 || d == 64) && N % 32 == 0; }
+
 bool attention_supported(int C, int heads, int N) {
-    if (heads <= 0 || C % heads) return false;
+    if (heads <= 0 || C % heads || N <= 0) return false;
     const int d = C / heads;
-    return (d == 32 || d == 64) && N % 32 == 0 && N > 0;
+    return attention_fast_path(d, N) || d <= 128;
 }
 
 // planes: 0 = the fp32-MFMA kernel; 2 = the fp16-matrix-pipe kernel with split operands (q, k, v must fit the fp16 range: the
@@ -315,8 +358,15 @@ bool attention_supported(int C, int heads, int N) {
 hipError_t launch_attention(const float* qkv, float* out, int B, int C, int heads, int N, hipStream_t s, int planes) {
     if (!attention_supported(C, heads, N)) return hipErrorInvalidValue;
     const int d = C / heads;
-    const dim3 g((N / 32 + 3) / 4, heads, B);
     const float scale = 1.0f / sqrtf((float)d);
+    if (!attention_fast_path(d, N)) {  // (fp32 whatever the mode: at least as accurate as any of them)
+        const dim3 gg((N + 63) / 64, heads, B);
+        if (d <= 32) attention_generic_kernel<32><<<gg, 64, 0, s>>>(qkv, out, C, d, N, scale);
+        else if (d <= 64) attention_generic_kernel<64><<<gg, 64, 0, s>>>(qkv, out, C, d, N, scale);
+        else attention_generic_kernel<128><<<gg, 64, 0, s>>>(qkv, out, C, d, N, scale);
+        return hipGetLastError();
+    }
+    const dim3 g((N / 32 + 3) / 4, heads, B);
     if (planes == 2) {
         if (d == 64) attention_f16x2_kernel<64, 2><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
         else attention_f16x2_kernel<32, 2><<<g, 256, 0, s>>>(qkv, out, C, N, scale);

@@ -240,7 +240,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
-            bv[m][r] = (bu + cu)[co_u + cu + 4 * hi < p.Cout ? 4 * hi : 0];
+            // (a tile may reach past the last output channel -- Cout < tile: the wave-uniform base stays on an existing channel too, not only the lane offset)
+            bv[m][r] = (bu + (co_u + cu < p.Cout ? cu : 0))[co_u + cu + 4 * hi < p.Cout ? 4 * hi : 0];
         }
 #pragma unroll
     for (int n0 = 0; n0 < NR; n0 += EPI_N) {
@@ -260,7 +261,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
-                        rv[j][m][r] = (ru + (long)cu * HW)[co_u + cu + 4 * hi < p.Cout ? loff[j] : 0];
+                        rv[j][m][r] = (ru + (long)(co_u + cu < p.Cout ? cu : 0) * HW)[co_u + cu + 4 * hi < p.Cout ? loff[j] : 0];
                     }
             }
         }

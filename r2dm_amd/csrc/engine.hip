@@ -376,6 +376,13 @@ struct Ctx {
 
     bool dry() const { return ar->dry; }
     void note(hipError_t e, const char* w) {
+        static const bool debug_sync = getenv("R2DM_DEBUG_SYNC") != nullptr;  // fault hunting: wait for and name every launch
+        if (debug_sync && e == hipSuccess && !dry()) {
+            fprintf(stderr, "[r2dm] %s ...", w);
+            fflush(stderr);
+            e = hipStreamSynchronize(st);
+            fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+        }
         if (e != hipSuccess && err == hipSuccess) {
             err = e;
             where = w;
@@ -536,6 +543,10 @@ struct Ctx {
                     (void)hipEventRecord(e0, st);
                 }
             }
+            if (getenv("R2DM_DEBUG_SYNC"))
+                fprintf(stderr, "[r2dm] conv algo %d %d->%d taps %d co_tile %d %dx%d B %d pro %d x %p/%p (c0 %d) y %p res %p aff %p stat %p ws [%p, +%zu)\n", p.algo, p.Cin,
+                        p.Cout, p.taps, p.co_tile, H, W, B, pro, (const void*)p.x.p0, (const void*)p.x.p1, p.x.c0, (void*)p.y, (const void*)p.res, (const void*)p.aff,
+                        (void*)p.stat, (void*)ar->base, ar->cap);
             note(launch_conv(p, st), "conv");
             if (e1) (void)hipEventRecord(e1, st);
         }
@@ -758,7 +769,7 @@ int check_config(const r2dm_config& c) {
         if (2 * Cl[i] == Cl[i - 1]) return fail(1, "channel_multiplier: 2*%d == %d makes u_block%d's first skip an identity over a concatenation (unsupported)", Cl[i], Cl[i - 1], i);
     const int N = (c.height / 8) * (c.width / 8);
     if (!attention_supported(Cl[4], c.attn_num_heads, N) || !attention_supported(Cl[3], c.attn_num_heads, N))
-        return fail(1, "attention: head_dim must be 32 or 64 and tokens a multiple of 32 (got C=%d/%d, heads=%d, N=%d)",
+        return fail(1, "attention: the head size must divide the channels and be at most 128 (got C=%d/%d, heads=%d, N=%d)",
                     Cl[4], Cl[3], c.attn_num_heads, N);
     return 0;
 }

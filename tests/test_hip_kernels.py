@@ -35,7 +35,8 @@ def sd(O):
 
 # all distinct (Cin, Cout, H, W) conv shapes of the 64x1024 network at B=1,
 # spatial size reduced 4x per axis where the full map would take the CPU oracle too long
-CONV3 = [(34, 64, 16, 256), (64, 64, 16, 256), (64, 128, 16, 256), (128, 64, 16, 256), (64, 2, 16, 256),
+CONV3 = [(16, 16, 8, 64), (48, 24, 8, 64),  # fewer output channels than the 32-channel tile (round 3: the residual / bias base pointers)
+         (34, 64, 16, 256), (64, 64, 16, 256), (64, 128, 16, 256), (128, 64, 16, 256), (64, 2, 16, 256),
          (128, 128, 8, 128), (128, 256, 8, 128), (256, 64, 8, 128), (256, 256, 16, 256), (256, 512, 4, 64),
          (512, 128, 4, 64), (512, 512, 8, 128), (512, 256, 8, 128), (40, 72, 12, 96), (64, 64, 2, 16),
          (16, 3, 7, 36), (64, 4, 9, 260)]  # few-output (direct) kernel: odd heights, widths that are not a multiple of its 256-column block
@@ -219,7 +220,8 @@ def test_fir_golden(golden, H):
     assert max_abs(H.fir_up2(x.to(DEV)).cpu(), g["up_y"]) < 1e-6
 
 
-@pytest.mark.parametrize("B,C,N", [(2, 512, 1024), (2, 256, 1024), (1, 512, 32), (1, 256, 4096), (3, 256, 96)])
+@pytest.mark.parametrize("B,C,N", [(2, 512, 1024), (2, 256, 1024), (1, 512, 32), (1, 256, 4096), (3, 256, 96),
+                                   (2, 768, 128), (2, 192, 16), (1, 128, 50), (1, 1024, 40)])  # head sizes 96 / 24 / 16 / 128, odd token counts: the generic kernel
 def test_attention(O, H, B, C, N):
     qkv = rnd(40, B, 3 * C, N)
     qkv[:, :, 5] *= 4.0  # a spiky token: forces running-max updates in the online softmax

@@ -53,7 +53,8 @@ def test_bad_geometry_is_refused():
     from r2dm_amd.unet import _Engine
 
     with pytest.raises(_lib.R2DMError, match="attention"):
-        _Engine(UNetGeometry.make(2, (16, 128), base_channels=8), 1)  # head_dim 8 / 4: unsupported
+        _Engine(UNetGeometry.make(2, (16, 128), base_channels=64, attn_num_heads=3), 1)  # 512 / 256 channels do not split into 3 heads
+    _Engine(UNetGeometry.make(2, (16, 128), base_channels=8), 1)  # head size 8 / 4: the generic attention kernel (round 3; was refused)
     with pytest.raises(_lib.R2DMError):
         _Engine(UNetGeometry.make(2, (20, 100), base_channels=64), 1)
 

@@ -103,6 +103,16 @@ def test_random_geometries_against_the_fp64_oracle():
     assert "12 cases, 0 failures" in r.stdout and " rejected" not in r.stdout, r.stdout[-3000:]
 
 
+def test_random_sampler_arguments_against_the_oracle():
+    """scripts/fuzz_sampler.py: random objective / mode / eta / schedule / step count / batch (also beyond max_batch) / RNG form / return_all
+    against the oracle's sampler on the same generators (profiles/r03_fuzz.txt); the reference's exceptions for a bad mode and a generator
+    list of the wrong length."""
+    env = dict(os.environ, SEED="5", CASES="10")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_sampler.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "10 cases, 0 failures" in r.stdout and r.stdout.count("Error OK") == 2, r.stdout[-3000:]
+
+
 def test_unsupported_channel_multiplier_is_rejected():
     """An up stage whose concatenated input equals its output width would take an identity skip over a concatenation."""
     import r2dm_amd

@@ -33,9 +33,10 @@ for case in range(N):
     shape_ok = tuple(got.shape) == tuple(want.shape) == ((S + 1, B, 2, *RES) if ra else (B, 2, *RES))
     d = (got - want).abs().flatten().double()
     q99 = torch.quantile(d[:: max(1, d.numel() // 200000)], 0.99).item(); rms = d.pow(2).mean().sqrt().item()
-    # DDIM with eta = 1: the reference's c_2 = sqrt(1 - alpha_s^2 - c_1^2) (continuous_time.py:224) cancels to alpha_t^2 sigma_s^2 / (alpha_s sigma_t)^2
-    # ~ 1e-7 at t = 1, so it carries a relative error of O(1) there and ANY two evaluations of the scalars (the product: host CPU, bit-identical
-    # to the reference's CPU run; this oracle: the device's libm) differ by ~3e-4 in c_2: a diffuse 1e-4 on the sample.  Looser bar, stated here.
+    # DDIM with eta = 1: the reference's c_2 = sqrt(1 - alpha_s^2 - c_1^2) (continuous_time.py:224) cancels: on the LAST step of a 4-step cosine
+    # schedule its float32 value is 2.3e-4 where float64 gives 7.4e-7 (the argument, 5e-8, is the rounding of 1 - ...), on the first 1.269e-3 vs
+    # 1.233e-3.  So c_2 there is rounding noise of ~1e-4, and two evaluations of the scalars (the product: host CPU, bit-identical to the
+    # reference's CPU run, tests/test_host.py; this oracle: the device's libm) differ by that much on the sample.  Looser bar, stated here.
     loose = mode == "ddim" and eta >= 1.0
     ok = shape_ok and bool(torch.isfinite(got).all()) and q99 < (3e-4 if loose else 2e-5) and rms < (3e-4 if loose else 2e-4)
     fails += (not ok); worst_q99 = max(worst_q99, q99)

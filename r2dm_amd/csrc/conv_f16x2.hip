@@ -383,32 +383,47 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         };
 
         // ---- prologue: ring stages 0..RING-2 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
+        // All 256 blocks start at once and the first pixels are a bandwidth burst (2 chunks x 32 KiB per CU = 16 MiB: 3-4 us of
+        // HBM; in-kernel timeline, profiles/r03_launch_overhead.txt), with the multipliers waiting at P.  So: what the first
+        // transform needs goes FIRST (the pixels of chunk 0, then this thread's (a, d) of chunk 0 -- read straight from global
+        // memory: the other waves' table writes are only published by P), everything else queues behind it (ring stages and table:
+        // L2 hits; the pixels of chunk 1), and the wait before the transform counts those as younger operations.
+        stamp(30);
         set_load_item(0);
         set_dma_item(0);
-#pragma unroll
-        for (int s = 0; s < RING - 1; ++s) dma_stage(s);
-        table_fetch(0);
         load_next(set0);
-        table_store(ic<0>{});  // (all stagers write their part of the first tile's table; read below through ...
-        use_set(set0, ic<0>{});
-        if (PRO != PRO_NONE) {  // ... this thread's own global load for chunk 0: the other waves' table writes are published by P)
+        if (PRO != PRO_NONE) {
             int cot0, b0, th0, tw0;
             decode(0, cot0, b0, th0, tw0);
             const unsigned char* a0 = sbase(reinterpret_cast<const float*>(p.aff) + (size_t)b0 * p.Cin * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gload(ad4[j], a0 + 16 * j, (unsigned)s_g * 64u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        table_fetch(0);
+        stamp(31);
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) dma_stage(s);
+        load_next(set1);  // (nchunks >= 4: the cursor stays inside the first tile)
+        constexpr int RING_NEWER = (RING - 1) * PPW;
+        use_set(set0, ic<RING_NEWER + NL>{});  // (ring stages and chunk 1 are younger)
+        stamp(32);
+        if (PRO != PRO_NONE) {
             asm volatile("" : "+v"(ad4[0]), "+v"(ad4[1]), "+v"(ad4[2]), "+v"(ad4[3]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) ad4[j] = set0.ok ? ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         transform_half(set0, 0, smem, false);
         transform_half(set0, 1, smem, false);
-        x_c = 1;          // (nchunks >= 4)
-        load_next(set1);  // (the cursor saturates: harmless for a one-tile, two-chunk block)
-        load_next(set0);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");  // chunk 1's pixels (and the ring stages before them)
+        x_c = 1;
+        stamp(33);
+        table_store(ic<RING_NEWER + NL>{});  // (all stagers write their part of the first tile's table: published by P)
+        load_next(set0);                     // chunk 2 (the cursor saturates: harmless for a one-tile, two-chunk block)
+        // P needs the ring stages and this wave's x writes; the pixels of chunk 1 may still be on their way -- iteration 0 waits for
+        // them itself (the multipliers get to their first taps that much earlier)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NL) : "memory");
+        stamp(34);
         __builtin_amdgcn_s_barrier();  // P
+        stamp(35);
         asm volatile("" ::: "memory");
 
         // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
@@ -424,7 +439,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
             if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
             dma_stage(3 * q + RING - 1);         // D0
-            use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago (q = 0: landed before P)
+            if (q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + PPW) : "memory");  // (only chunk 2 and D0 are younger than chunk 1)
+            use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago
             transform_half(cur, 0, nbuf);        // (past the end: the last chunk again, into the buffer nobody reads)
             stamp(10);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+1 landed
@@ -603,15 +619,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         asm volatile("" : "+v"(ln));
         return ln;
     };
-    auto res_request = [&](auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) {
+    auto res_request_to = [&](f32x4 (&rv)[4], auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) {
         if (!p.res) return;
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
         const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)(cot * CO_T) * HW);
 #pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) rv_e[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
+        for (int k8 = 0; k8 < 4; ++k8) rv[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
     };
+    auto res_request = [&](auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) { res_request_to(rv_e, QD, b, th, tw, cot, ln); };
     // the turn: this wave's accumulator quarter (m, n) -> dst[8-channel block][8 channels][32 pixels]
     auto turn_write = [&](auto QD, float* dst, int ln) __attribute__((always_inline)) {
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             for (int j = 0; j < 4; ++j) dst[k8 * 256 + (j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
     };
     // bias, residual, scale, store, statistics of one turned quarter (t[k8]: 4 consecutive pixels of channel 8 k8 + lane / 8)
-    auto quarter = [&](auto QD, const f32x4 (&t)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+    auto quarter = [&](auto QD, const f32x4 (&t)[4], const f32x4 (&rv)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
@@ -630,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             f32x4 v = t[k8] * wsc + bias_e[m * 4 + k8];
-            if (p.res) v = rv_e[k8] + v;
+            if (p.res) v = rv[k8] + v;
             v *= sc_blk;  // (1.0f without p.scale: exact)
             (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
             if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -656,16 +673,17 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         if (ln == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
         amax_e = 0.f;
     };
-    // deferred quarter S (1..3) of the pending tile
-    auto slice = [&](auto SS) __attribute__((always_inline)) {
+    // deferred quarter S (1..3) of the pending tile; its residual is in rv (between chunks: rv_e, and the next quarter's is
+    // requested here; at the block's end all three are requested up front)
+    auto slice_rv = [&](auto SS, const f32x4 (&rv)[4], auto NEXT) __attribute__((always_inline)) {
         constexpr int S = decltype(SS)::value;
         const int ln = fresh_lane();
         f32x4 t[4];
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + (S - 1) * 1024 + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
         float ps[4], pq[4];
-        quarter(SS, t, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq);
-        if (S < 3) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
+        quarter(SS, t, rv, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq);
+        if (S < 3 && decltype(NEXT)::value) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
         if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
         if (S == 2) {
 #pragma unroll
@@ -677,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             pending = false;
         }
     };
+    auto slice = [&](auto SS) __attribute__((always_inline)) { slice_rv(SS, rv_e, ic<1>{}); };
 
     auto chunk = [&](int q, auto PAR) __attribute__((always_inline)) {
         if constexpr (decltype(PAR)::value == 1) {
@@ -711,6 +730,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if constexpr (NPLK == 2) acc[m][n][r] = __builtin_fmaf(acl[m][n][r], LINV, acc[m][n][r]);
+                // (the block's last tile has nothing left to hide its deferred quarters behind: their residuals are requested now, into
+                // the registers the second accumulator has just left, and the quarters follow right below)
+                const bool last_tile = e_item + 1 == nIt;
+                f32x4 rv2[4] = {}, rv3[4] = {};
+                if (last_tile) {
+                    res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
+                    res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                }
                 // quarter 0 right away (through the 1 KiB patch, block by block), quarters 1..3 into the LDS area
                 {
                     f32x4 t[4];
@@ -724,12 +751,20 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     turn_write(ic<1>{}, dump, ln);
                     turn_write(ic<2>{}, dump + 1024, ln);
                     turn_write(ic<3>{}, dump + 2048, ln);
-                    quarter(ic<0>{}, t, e_b, e_th, e_tw, e_cot, ln, cs, cq);
+                    quarter(ic<0>{}, t, rv_e, e_b, e_th, e_tw, e_cot, ln, cs, cq);
                     res_request(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
                 }
                 pe_b = e_b; pe_th = e_th; pe_tw = e_tw; pe_cot = e_cot;
                 pending = true;
                 stamp(8);
+                if (last_tile) {
+                    slice_rv(ic<1>{}, rv_e, ic<0>{});
+                    stamp(41);
+                    slice_rv(ic<2>{}, rv2, ic<0>{});
+                    stamp(42);
+                    slice_rv(ic<3>{}, rv3, ic<0>{});  // (clears `pending`)
+                    stamp(43);
+                }
                 // both accumulators restart from C = 0 in the next tile's first products; the compiler cannot see that the
                 // "accumulate" branch is never taken there and would keep all 128 registers alive: an empty definition ends
                 // the old values' lives (no instruction)
@@ -743,18 +778,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         }
     };
 
+    stamp(36);
     __builtin_amdgcn_s_barrier();  // P: ring stages 0..RING-2 and chunk 0 staged
+    stamp(37);
     asm volatile("" ::: "memory");
     frag_first(lds_w0);
     for (int q = 0; q < Q; q += 2) {  // (Q is even: Cin % 32 == 0)
         chunk(q, ic<0>{});
         chunk(q + 1, ic<1>{});
-    }
-    if (pending) {  // the last tile's deferred quarters
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        slice(ic<1>{});
-        slice(ic<2>{});
-        slice(ic<3>{});
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // prefetched fragments must not outlive the block
     stamp_real(1);

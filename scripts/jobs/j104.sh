@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3: in-kernel timeline of small launches (one tile per block): where does the fixed per-launch cost go?
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/j104; mkdir -p $O
+cd $R
+
+for sh in U3_128_128 L1_64_64; do
+B=8 R2DM_HIP_LIB=$R/build_probe/lib_f2_prof.so MAXEV=14 SHAPES=$sh timeout 300 python scripts/f2_timeline.py 2>&1 | grep -v amdgpu > $O/tl_$sh.log; head -18 $O/tl_$sh.log
+done

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
     const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
     const int c0 = p.x.p1 ? p.x.c0 : p.Cin;
     const gcf wg = (gcf)p.w;
-#pragma unroll 2
+#ifndef DC_UNROLL
+#define DC_UNROLL 4  // (one wave per SIMD: the loads in flight hide the latency -- 2: 65.6 us, 4: 52.8 us, 8: 64.0 us at batch 8)
+#endif
+#pragma unroll DC_UNROLL
     for (int ci = 0; ci < p.Cin; ++ci) {
         const gcf pl = (gcf)(ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW);
         float x[R + 2][6];
@@ -151,6 +154,14 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
     const int S = p.stat_slots >> 1;
     double gs = 0.0, gq = 0.0;
     for (int co0 = 0; co0 < p.Cout; co0 += 8) {
+        // the block's eight residual vectors first: a load behind a store may not pass it (the output may alias the residual as far
+        // as the compiler knows), and one L2 round trip per channel -- 64 in series per wave -- was a third of this kernel's time
+        // (87 -> 59 us at batch 8; requesting them a whole block early as well: 59 us, not kept)
+        f32x4 rv[8] = {};
+        if (p.res) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) rv[o] = *(gcf4)(p.res + b * p.res_bs + (long)(co0 + o) * HW + pix);
+        }
         float acc[8][4];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
         for (int o = 0; o < 8; ++o) {
             const float bo = ((gcf)p.bias)[co0 + o];
             f32x4 v = f32x4{acc[o][0] + bo, acc[o][1] + bo, acc[o][2] + bo, acc[o][3] + bo};
-            if (p.res) v = *(gcf4)(p.res + b * p.res_bs + (long)(co0 + o) * HW + pix) + v;
+            if (p.res) v = rv[o] + v;
             v *= sc;  // (1.0f without p.scale: exact)
             if (active) {
                 *(gf4)(p.y + b * p.y_bs + (long)(co0 + o) * HW + pix) = v;

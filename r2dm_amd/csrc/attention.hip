@@ -261,13 +261,17 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
             }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            // (the running maximum settles after a few tiles: alpha == 1 in every lane from then on, and multiplying by exactly 1 is
+            // the identity -- the 2 x 16 x TB multiplications are skipped wave-uniformly: a seventh of the loop's vector instructions)
+            if (__any(alpha != 1.0f)) {
 #pragma unroll
-            for (int t = 0; t < TB; ++t)
+                for (int t = 0; t < TB; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o[t][r] *= alpha;
-                    ol[t][r] *= alpha;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        o[t][r] *= alpha;
+                        ol[t][r] *= alpha;
+                    }
+            }
             // P^T: registers 8 st .. 8 st + 7 are this lane's eight keys of k-step st (see the V layout above)
             const unsigned char* vb = Vs + buf * VBUF + l31 * VROW + hi * 16;
 #pragma unroll

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // NPLK = 1: the h planes alone -- one fp16 product per MAC (Q, K, V and P rounded to fp16, fp32 accumulation and softmax): the
 // reduced-precision bulk mode (conv_f16x2.hip).
 template <int D, int NPLK>
-__global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N,
+__global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N,
                                                               float scale) {
     constexpr int KROW = D * 2 + 16, VROW = 32 * 2 + 16;          // bytes per LDS row (16 bytes of padding: conflict-free b128 reads)
     constexpr int KPL = 32 * KROW, VPL = D * VROW;                 // bytes per plane
@@ -217,33 +217,42 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
         }
     };
 
+    // S^T of a key tile into (s, sl): issued BEHIND the barrier that publishes the tile, i.e. at the end of the previous iteration --
+    // its 3 KS MFMAs run while this wave stages the next tile (split + LDS writes: independent vector work), and the softmax
+    // that needs them comes after that.  (Round 2's order, stage | S^T | softmax | O^T | barrier, exposed the matrix-pipe and LDS
+    // latencies of both contractions in every iteration: ablation timings in profiles/r03_launch_overhead.txt.)
+    f32x16 s, sl;
+    auto scores = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* kb = Kt + buf * KBUF + l31 * KROW + hi * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = sl[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32));
+            const f16x8 qhh = __builtin_bit_cast(f16x8, qh[st]), qll = __builtin_bit_cast(f16x8, ql[st]);
+            if (NPLK == 2) {
+                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32 + KPL));
+                sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qhh, sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qll, sl, 0, 0, 0);
+            }
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qhh, s, 0, 0, 0);
+        }
+    };
     const int ntiles = N / 32;
     load_tile(0);
     store_tile(0);
     if (ntiles > 1) load_tile(1);
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = sl[r] = 0.f;
+    if (active) scores(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ntiles) {
-            store_tile(buf ^ 1);  // (buffer of tile kt-1: everybody left it at the barrier that ended the previous iteration)
+            store_tile(buf ^ 1);  // (buffer of tile kt-1: everybody left it at the barrier in the middle of the previous iteration)
             if (kt + 2 < ntiles) load_tile(kt + 2);
         }
         if (active) {
-            const unsigned char* kb = Kt + buf * KBUF + l31 * KROW + hi * 16;
-            f32x16 s, sl;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = sl[r] = 0.f;
-#pragma unroll
-            for (int st = 0; st < KS; ++st) {
-                const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32));
-                const f16x8 qhh = __builtin_bit_cast(f16x8, qh[st]), qll = __builtin_bit_cast(f16x8, ql[st]);
-                if (NPLK == 2) {
-                    const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kb + st * 32 + KPL));
-                    sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qhh, sl, 0, 0, 0);
-                    sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qll, sl, 0, 0, 0);
-                }
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qhh, s, 0, 0, 0);
-            }
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -293,7 +302,8 @@ __global__ __launch_bounds__(256) void attention_f16x2_kernel(const float* __res
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();  // tile kt + 1 is in LDS; everybody is done with tile kt
+        if (active && kt + 1 < ntiles) scores(buf ^ 1);
     }
     if (!active) return;
     const float l_tot = l_run + wave_xor32(l_run);

@@ -5,7 +5,7 @@
 // (conv_mfma.hip); this kernel is the flash-style core on the channel-major layout those produce:
 //   qkv (B, 3C, N): rows [0,C) = Q, [C,2C) = K, [2C,3C) = V, head h owns rows h*D .. h*D+D-1
 //   out (B, C, N)
-// One wave owns 32 queries; a block (4 waves) shares each 32-key K/V tile through LDS.
+// One wave owns 32 queries; a block (4 waves; 8 in the fp16-pipe kernel) shares each 32-key K/V tile through LDS.
 //   S^T = K^T Q   (M = keys, N = queries, K = d): the MFMA result leaves every lane holding 16
 //                  scores of ONE query (column = lane&31), so the online softmax is lane-local plus
 //                  one cross-half shuffle, and P^T is already the B operand of the next product;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // NPLK = 1: the h planes alone -- one fp16 product per MAC (Q, K, V and P rounded to fp16, fp32 accumulation and softmax): the
 // reduced-precision bulk mode (conv_f16x2.hip).
 template <int D, int NPLK>
-__global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N,
+__global__ __launch_bounds__(512) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N,
                                                               float scale) {
     constexpr int KROW = D * 2 + 16, VROW = 32 * 2 + 16;          // bytes per LDS row (16 bytes of padding: conflict-free b128 reads)
     constexpr int KPL = 32 * KROW, VPL = D * VROW;                 // bytes per plane
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = tid >> 6;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int q0 = (blockIdx.x * 8 + wave) * 32;  // (eight waves = 256 queries share every staged K / V tile)
     const bool active = q0 < N;
 
     const float* qp = qkv + ((long)b * 3 * C + (long)h * D) * N;
@@ -176,10 +176,11 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
         for (int r = 0; r < 16; ++r) o[t][r] = ol[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging roles: K -- thread (key = tid & 31, d block = tid >> 5) moves 8 d of one key; V -- thread (d = tid >> 2, key octet
-    // = tid & 3) moves 8 consecutive keys of one d.  Threads beyond D / 8 d blocks (D = 32: half of them) idle.
-    const int k_key = tid & 31, k_db = tid >> 5, v_d = tid >> 2, v_kq = tid & 3;
-    const bool k_on = k_db < D / 8, v_on = v_d < D;
+    // staging roles: threads 0..255 move K -- thread (key = t & 31, d block = t >> 5) 8 d of one key --, threads 256..511 move V --
+    // thread (d = t >> 2, key octet = t & 3) 8 consecutive keys of one d.  Threads beyond D / 8 d blocks (D = 32: half of them) idle.
+    const int t8 = tid & 255;
+    const int k_key = t8 & 31, k_db = t8 >> 5, v_d = t8 >> 2, v_kq = t8 & 3;
+    const bool k_on = tid < 256 && k_db < D / 8, v_on = tid >= 256 && v_d < D;
     float kreg[8];
     f32x4 vreg[2];
     auto load_tile = [&](int kt) {
@@ -380,13 +381,13 @@ hipError_t launch_attention(const float* qkv, float* out, int B, int C, int head
         else attention_generic_kernel<128><<<gg, 64, 0, s>>>(qkv, out, C, d, N, scale);
         return hipGetLastError();
     }
-    const dim3 g((N / 32 + 3) / 4, heads, B);
+    const dim3 g((N / 32 + 3) / 4, heads, B), g8((N / 32 + 7) / 8, heads, B);
     if (planes == 2) {
-        if (d == 64) attention_f16x2_kernel<64, 2><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
-        else attention_f16x2_kernel<32, 2><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+        if (d == 64) attention_f16x2_kernel<64, 2><<<g8, 512, 0, s>>>(qkv, out, C, N, scale);
+        else attention_f16x2_kernel<32, 2><<<g8, 512, 0, s>>>(qkv, out, C, N, scale);
     } else if (planes == 1) {
-        if (d == 64) attention_f16x2_kernel<64, 1><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
-        else attention_f16x2_kernel<32, 1><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
+        if (d == 64) attention_f16x2_kernel<64, 1><<<g8, 512, 0, s>>>(qkv, out, C, N, scale);
+        else attention_f16x2_kernel<32, 1><<<g8, 512, 0, s>>>(qkv, out, C, N, scale);
     } else {
         if (d == 64) attention_kernel<64><<<g, 256, 0, s>>>(qkv, out, C, N, scale);
         else attention_kernel<32><<<g, 256, 0, s>>>(qkv, out, C, N, scale);

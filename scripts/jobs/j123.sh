@@ -28,5 +28,5 @@ for r in csv.DictReader(open('$f')):
 done 2>&1 | tee $O/kernels.log
 for rep in 1 2 3; do for lib in build_probe/lib_head.so r2dm_amd/libr2dm_hip.so; do
 R2DM_HIP_LIB=$R/$lib timeout 300 python $R/bench.py --steps 64 --warmup 4 --no-cpu-baseline --no-torch-baseline --no-exact-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$lib:', round(j['ms_per_step'],3), r['board']['sclk_mhz'], r['board']['board_w'])"; done; done 2>&1 | tee $O/ab.log
-R2DM_HIP_LIB=$R/build_probe/lib_head.so timeout 300 python $R/bench.py --config 4 --steps 8 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-exact-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('config 4, previous library:', round(j['ms_per_step'],3), round(j['value'],4))" | tee -a $O/ab.log
-timeout 300 python $R/bench.py --config 4 --steps 8 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-exact-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('config 4, this library:', round(j['ms_per_step'],3), round(j['value'],4))" | tee -a $O/ab.log
+
+

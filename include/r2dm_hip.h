@@ -133,6 +133,10 @@ int r2dm_q_step(const float* x_s, const float* noise, const float* coef, float* 
  *    ray_angles (2,H,W) [elevation, azimuth] in rad, out (B,5,H,W) = depth,x,y,z,reflectance. */
 int r2dm_lidar_postprocess(const float* x, const float* ray_angles, float* out, int32_t batch, int32_t height,
                            int32_t width, float min_depth, float max_depth, void* stream);
+/* ... with the checkpoint's depth coding (LiDARUtility.revert_depth, utils/lidar.py:95-112):
+ *    depth_format 0 = "log_depth" (the entry above), 1 = "inverse_depth", 2 = "depth". */
+int r2dm_lidar_postprocess_fmt(const float* x, const float* ray_angles, float* out, int32_t batch, int32_t height,
+                               int32_t width, float min_depth, float max_depth, int32_t depth_format, void* stream);
 
 /* -- single kernels, exported for per-op parity tests against the oracle -------------------- */
 /* ops.Conv2d(ring) 3x3 / 1x1 (models/ops.py:149-173) with optional fused GroupNorm-affine(+SiLU)

@@ -20,6 +20,10 @@ class R2DMError(RuntimeError):
     pass
 
 
+class R2DMRangeError(R2DMError):
+    """The fp16-operand paths' range guard tripped (r2dm_check_range): results of the forwards since the last check are not valid."""
+
+
 class Config(Structure):
     _fields_ = [
         ("in_channels", c_int32),
@@ -65,6 +69,7 @@ SIGNATURES = {
     "r2dm_repaint_blend": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
     "r2dm_q_step": (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P]),
     "r2dm_lidar_postprocess": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_float, c_float, _P]),
+    "r2dm_lidar_postprocess_fmt": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_float, c_float, c_int32, _P]),
     "r2dm_conv_packed_elems": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "r2dm_conv2d_ring": (c_int32, [_P, _P, _P, _P, _P, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_int32, _P]),
@@ -160,12 +165,17 @@ def q_step(x_s, noise, coef) -> torch.Tensor:
     return out
 
 
-def lidar_postprocess(x, ray_angles, min_depth: float, max_depth: float) -> torch.Tensor:
+DEPTH_FORMATS = {"log_depth": 0, "inverse_depth": 1, "depth": 2}
+
+
+def lidar_postprocess(x, ray_angles, min_depth: float, max_depth: float, depth_format: str = "log_depth") -> torch.Tensor:
     require_gpu(x, "x")
+    if depth_format not in DEPTH_FORMATS:
+        raise ValueError(f"unknown depth_format {depth_format!r}")
     x, ang = f32c(x), f32c(ray_angles).reshape(2, *x.shape[-2:])
     B, _, H, W = x.shape
     out = torch.empty(B, 5, H, W, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        check(lib().r2dm_lidar_postprocess(ptr(x), ptr(ang), ptr(out), B, H, W, float(min_depth), float(max_depth),
-                                           stream_ptr(x.device)))
+        check(lib().r2dm_lidar_postprocess_fmt(ptr(x), ptr(ang), ptr(out), B, H, W, float(min_depth), float(max_depth),
+                                               DEPTH_FORMATS[depth_format], stream_ptr(x.device)))
     return out

@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libr2dm_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-inline-asm"
 mkdir -p build
 pids=()
 for f in conv_mfma conv_bf16x3 conv_f16x2 proj_f16x2 conv_direct norm resample attention embed posterior engine; do

@@ -46,7 +46,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // ---- kernel launchers (each in its own .hip) ------------------------------------------
 
-enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2 };
+// PRO_PRESPLIT (conv_f16x2 only): the input is the pre-split tensor of presplit.hip -- affine / SiLU / f16 split already applied
+enum Prologue { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_SILU = 2, PRO_PRESPLIT = 3 };
 // ALGO_F32: fp32-input MFMA (conv_mfma.hip).  ALGO_BF16X3: fp32 operands split exactly into three bf16 pieces, six
 // bf16 MFMA products per fp32 product, fp32 accumulation (conv_bf16x3.hip) -- same accuracy class, 2.7x fewer
 // matrix-pipe cycles; needs 3x3, Cin % 16 == 0, Cout % 64 == 0.
@@ -110,14 +111,22 @@ long conv_bf16x3_packed_floats(int Cin, int Cout);
 int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);
 hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, int co_tile, hipStream_t s);
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s);
-bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
+bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile = 64);  // co_tile: 64 | 128 (conv_f16x2.hip)
 long conv_f16x2_packed_floats(int Cin, int Cout);
+// 128-channel output tiles (one accumulator) where the launch still has a tile per CU at the planned batch, else 64 (two accumulators);
+// env R2DM_F2_CO_TILE = 64 | 128 forces one of them where the shape allows (experiments, per-kernel tests)
+int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch);
 // range_flag (device int, may be nullptr): bit 0 is set if a weight does not fit the fp16 range
 // wscale (device float[2], may be nullptr = unscaled): [0] scratch (max|w| as float bits), [1] <- the inverse of the power-of-two
 // scale applied to the layer's weights (ConvParams::wscale points there)
-hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr);
+hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr, int co_tile = 64);
 hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream_t s);  // max_bits <- float bits of max|w| (zeroed first)
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s);
+// the operand pre-pass of conv_f16x2 (presplit.hip): xs <- [b][chunk][plane][group][H + 2][W][8 ch] fp16 of silu(x a + d) (prologue as in
+// ConvParams); a convolution with prologue = PRO_PRESPLIT and x.p0 = xs, x.bs0 = presplit_floats(1, Cin, H, W) consumes it
+long presplit_floats(int B, int Cin, int H, int W);
+bool presplit_supported(const Src& x, int Cin, int H, int W);
+hipError_t launch_presplit(const Src& x, const float2* aff, int prologue, float* xs, int B, int Cin, int H, int W, hipStream_t s);
 bool proj_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
 long proj_f16x2_packed_floats(int Cin, int Cout);
 hipError_t launch_pack_proj_f16x2(const float* w_oi, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr);
@@ -195,6 +204,6 @@ hipError_t launch_q_step(const float* x, const float* noise, const float* coef, 
 
 // (B,2,H,W) in [-1,1] -> (B,5,H,W) [depth, x, y, z, reflectance]  (reference sample_and_save.py:52-57)
 hipError_t launch_lidar_postprocess(const float* x, const float* angles, float* y, int B, int H, int W,
-                                    float min_depth, float max_depth, hipStream_t s);
+                                    float min_depth, float max_depth, hipStream_t s, int depth_format = 0);  // 0 log_depth, 1 inverse_depth, 2 depth
 
 }  // namespace r2dm

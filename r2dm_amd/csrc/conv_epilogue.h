@@ -108,8 +108,10 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
     if ((lane & 7) == 0 && (k8 & (bin - 1)) == 0) {
         const int S = p.stat_slots >> 1;
         const int slot = (th * nTw + tw) * 4 + wave_px;
-        const int g = p.stat_goff + (co_half + k8 * 8) / p.stat_cpg;
-        const int half = bpg == 8 ? (co_half % p.stat_cpg) / 32 : 0;
+        // (bpg is 1, 2, 4 or 8 here -- a power of two: shifts, not the ~40 instructions of two integer divisions per half)
+        const int sh = 3 + (bpg >= 2) + (bpg >= 4) + (bpg >= 8);  // log2(stat_cpg)
+        const int g = p.stat_goff + ((co_half + k8 * 8) >> sh);
+        const int half = bpg == 8 ? (co_half & (p.stat_cpg - 1)) >> 5 : 0;
         gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2);
         o[2 * S * half + kind] = t;
         if (bpg < 8) o[2 * S + kind] = 0.0;

@@ -49,15 +49,23 @@ constexpr int NPL = 2;                                      // planes: h, l
 constexpr int XS = 67;                                      // 66 columns + 1 dump column (never read)
 constexpr int XPL = NG * XR * XS;                           // 16-byte entries per plane
 constexpr int XBYTES = NPL * XPL * 16;                      // 25728
-constexpr int WSTAGE = NPL * 3 * NG * CO_T * 16;            // 12288: one kernel row of one chunk
-constexpr int RING = 4;
-constexpr int WB0 = 2 * XBYTES;                             // [x buffer 0][x buffer 1][weight ring][epilogue patches][finished tile][(a, d) table]
-constexpr int PATCH0 = WB0 + RING * WSTAGE;                 // 100608
-constexpr int RESQ = 3;                                     // quarters of a finished tile that wait in LDS for their deferred epilogue (of 4)
-constexpr int RES0 = PATCH0 + 4 * 1024;                     // 104704: four waves x RESQ x 4 KiB
-constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;              // 153856: (a, d) of the current tile's sample, all Cin channels
-constexpr int ADTAB_BYTES = 4096;                           // Cin <= 512
-constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;             // 157952
+constexpr int ADTAB_BYTES = 4096;                           // (a, d) of the current tile's sample, all Cin channels: Cin <= 512
+// MRK = 32-channel row blocks per multiplying wave: 2 = 64-channel output tiles, two accumulators per MFMA tile (round 2);
+// 4 = 128-channel output tiles, ONE accumulator (round 4: half the staging work and x-fragment reads per MFMA)
+template <int MRK>
+struct Geo {
+    static constexpr int COT = 32 * MRK;                        // output channels per tile
+    static constexpr int WSTAGE = NPL * 3 * NG * COT * 16;      // 12288 / 24576: one kernel row of one chunk
+    static constexpr int RING = MRK == 2 ? 4 : 3;               // weight stages in LDS
+    static constexpr int WB0 = 2 * XBYTES;                      // [x buffer 0][x buffer 1][weight ring][epilogue patches][finished tile][(a, d) table]
+    static constexpr int PATCH0 = WB0 + RING * WSTAGE;          // 100608 / 125184
+    static constexpr int RESQ = MRK == 2 ? 3 : 2;               // quarters of a finished tile that wait in LDS for their deferred epilogue (per wave; of 4 / of 8)
+    static constexpr int RES0 = PATCH0 + (MRK == 2 ? 4 * 1024 : 0);  // four waves x RESQ x 4 KiB (wide tile: no separate patches -- the turn of the immediate
+                                                                // quarters goes through the wave's first waiting slot, which is empty at a tile's end)
+    static constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;
+    static constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;      // 157952 / 162048
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS");
+};
 }  // namespace f2
 
 // Reciprocals for the tile decode (host: f2_magic): x / d == __umulhi(x, m) exactly for x * d < 2^32, m = floor(2^32 / d) + 1
@@ -72,19 +80,30 @@ static unsigned f2_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ull
 // 1 = the h plane alone, ONE fp16 product per MAC with fp32 accumulation -- the reduced-precision bulk mode that mirrors the
 // reference's fp16 autocast sampler (/root/reference/sample_and_save.py:70, utils/option.py:49): same packing, same tiles,
 // the l plane is neither fetched, computed nor multiplied.
-template <int PRO, int NPLK>
+template <int PRO, int NPLK, int MRK>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
     static_assert(NPLK == 1 || NPLK == 2, "planes");
-    // NPLK == 2: 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager.  NPLK == 1: 4 MFMAs per tap; the h
-    // plane is the first 6 pieces of a stage: stager w fetches pieces w and w + 2 (pieces 2 and 3 twice: harmless)
-    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = NPLK == 2 ? 3 : 2;
+    static_assert(MRK == 2 || MRK == 4, "row blocks per multiplying wave");
+    using GEO = Geo<MRK>;
+    constexpr int MR = MRK, COT = GEO::COT, WSTAGE = GEO::WSTAGE, RING = GEO::RING, WB0 = GEO::WB0, PATCH0 = GEO::PATCH0, RESQ = GEO::RESQ,
+                  RES0 = GEO::RES0, ADTAB0 = GEO::ADTAB0;
+    // the cross products go to a second accumulator (scaled l planes) or, in the wide tile, to the same one (l planes at their true scale)
+    constexpr bool ACC2 = NPLK == 2 && MRK == 2;
+    constexpr bool LSCALED = MRK == 2;
+    // MRK == 2 -- NPLK == 2: 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager.  NPLK == 1: 4 MFMAs per tap; the h
+    // plane is the first 6 pieces of a stage: stager w fetches pieces w and w + 2 (pieces 2 and 3 twice: harmless).
+    // MRK == 4 -- NPLK == 2: 24 MFMAs per tap, 24 pieces per stage, six per stager; NPLK == 1: 8 MFMAs, the h plane = 12 pieces, three per stager
+    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = MRK == 2 ? (NPLK == 2 ? 3 : 2) : (NPLK == 2 ? 6 : 3);
     constexpr int NL = 8;                         // global loads per chunk of raw pixels (the folded affine comes from an LDS table)
     constexpr int PER_ITER = 3 * PPW + NL;        // VMEM operations a stager issues per chunk
-    // a weight stage requested at the start of segment j is due at the end of segment j + RING - 2: this many younger
-    // operations of the stager may still be in flight then (vmcnt retires in order; the queue holds loads only)
-    constexpr int STAGE_NEWER = RING == 8 ? 2 * PER_ITER : 2 * PPW + NL;
-    static_assert(RING == 4 || RING == 8, "ring depth");
+    // A weight stage must have landed when the barrier in front of its first read is reached; this many younger operations of the
+    // stager may still be in flight then (vmcnt retires in order; the queue holds loads only).  Per iteration the queue is
+    //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw [NL] | #3
+    // RING == 4: the stage due at #1 is D1 of the previous iteration, at #2 its D2, at #3 this iteration's D0 -- 2 PPW + NL younger each time.
+    // RING == 3 (one segment less of flight): due at #1 is the previous D2 (raw, D0 younger), at #2 D0 (D1), at #3 D1 (D2, raw).
+    constexpr int NEWER1 = RING == 4 ? 2 * PPW + NL : NL + PPW, NEWER2 = RING == 4 ? 2 * PPW + NL : PPW, NEWER3 = RING == 4 ? 2 * PPW + NL : PPW + NL;
+    static_assert(RING == 4 || RING == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
 
@@ -97,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     const int H = p.H, W = p.W;
     const int HW = H * W;
     const int nTw = W / TW, nTh = H / TH;  // whole tiles only (launcher)
-    const int nCoT = p.Cout / CO_T;
+    const int nCoT = p.Cout / COT;
     const int nchunks = p.Cin / CK, nst = 3 * nchunks;
     const int G = gridDim.x;
     const int nIt = (total_tiles - (int)blockIdx.x + G - 1) / G;  // tiles of this block (grid <= total_tiles)
@@ -140,6 +159,159 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     if (helper) {
         // ============================================= staging waves =============================================
         __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL: f16 conversions saturate at +-65504
+        // ---- weights: LDS-DMA cursor (stage within the tile's co tile; tiles may change co tile) ----
+        // 12 pieces of 1 KiB per stage; stager w issues pieces 3w, 3w+1, 3w+2.  Everything but the lane offset is wave-uniform:
+        // source and LDS base go through SGPRs.
+        const unsigned lane16 = (unsigned)lane * 16;
+        int d_item = 0, d_s = 0;
+        const unsigned char* d_base = nullptr;
+        auto set_dma_item = [&](int it) __attribute__((always_inline)) {
+            int cot, b, th, tw;
+            decode(it, cot, b, th, tw);
+            d_base = wsrc + (size_t)cot * nst * WSTAGE;
+        };
+        // the cursor's stage -> its ring slot (stage number q3 + K, q3 a multiple of 3: with RING == 3 the slot is K % 3 statically); this
+        // wave's PPW pieces; advances the cursor (past the end: the last stage again -- harmless, keeps the vmcnt bookkeeping uniform)
+        auto dma_stage = [&](int q3, auto KK) __attribute__((always_inline)) {
+            constexpr int K = decltype(KK)::value;
+            const unsigned l16 = lane16, l0 = lds0;  // (odr-used here: clang does not capture variables that a generic lambda only names inside if constexpr)
+            const int wv = wave;
+            const int slot = RING == 4 ? ((q3 + K) & 3) : K % 3;
+            const unsigned long long sv = (unsigned long long)(d_base + (size_t)d_s * WSTAGE);  // wave-uniform: say so (SGPR operand)
+            const unsigned char* src = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
+                                                              (unsigned)__builtin_amdgcn_readfirstlane((int)sv));
+            if (d_s + 1 < nst)
+                ++d_s;
+            else if (d_item + 1 < nIt) {
+                d_s = 0;
+                set_dma_item(++d_item);
+            }
+#ifdef F2_NO_DMA  // timing ablation (wrong results)
+            if (slot >= 0) return;
+#endif
+            // one M0 set-up per group of pieces, the instruction offset advances the global and the LDS address together
+            if constexpr (PPW == 3) {  // pieces 3w, 3w+1, 3w+2 (64-channel tiles: the whole stage; 128-channel tiles, one plane: the h plane)
+                const unsigned char* s3 = src + wv * (PPW * 1024);
+                const unsigned d3 = l0 + WB0 + (unsigned)(slot * WSTAGE + wv * (PPW * 1024));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:2048"
+                             :
+                             : "v"(l16), "s"(s3), "s"(d3)
+                             : "memory", "m0");
+            } else if constexpr (PPW == 6) {  // 128-channel tiles, both planes: pieces 6w .. 6w+5 (the instruction offset ends at 4095)
+                const unsigned char* s3 = src + wv * (PPW * 1024);
+                const unsigned d3 = l0 + WB0 + (unsigned)(slot * WSTAGE + wv * (PPW * 1024));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:3072"
+                             :
+                             : "v"(l16), "s"(s3), "s"(d3)
+                             : "memory", "m0");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:1024"
+                             :
+                             : "v"(l16), "s"(s3 + 4096), "s"(d3 + 4096u)
+                             : "memory", "m0");
+            } else {  // 64-channel tiles, the h plane only (6 KiB at the start of the stage): pieces w and w + 2
+                const unsigned char* s3 = src + wv * 1024;
+                const unsigned d3 = l0 + WB0 + (unsigned)(slot * WSTAGE + wv * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:2048"
+                             :
+                             : "v"(l16), "s"(s3), "s"(d3)
+                             : "memory", "m0");
+            }
+        };
+
+
+        if constexpr (PRO == PRO_PRESPLIT) {
+            // ---- pre-split input (presplit.hip): affine, SiLU and the f16 split were applied ONCE, by a pre-pass that wrote the two
+            // planes as [b][chunk][plane][group][H + 2][W][8 ch]; the x tile of a chunk is NPIECE LDS-DMA pieces of 1 KiB whose lanes
+            // address their own entry (tile row outside the image: the layout's zero rows; azimuth wrap: a lane address).  No pixel
+            // loads, no transform, no LDS writes: ~16 DMA instructions per chunk and wave.  Queue of one iteration:
+            //   D0 [PPW], x(q+1) [PPX] | #1 | D1 [PPW] | #2 | D2 [PPW] | #3        (x(q+1) has three segments to land)
+            static_assert(MRK == 2 && RING == 4, "pre-split input: 64-channel tiles");
+            constexpr int NENT = NPLK * XPL, NPIECE = (NENT + 63) / 64, PPX = (NPIECE + 3) / 4;
+            const int plane_px = (H + 2) * W;  // 16-byte entries per (plane, group)
+            const unsigned chunk_bytes = (unsigned)(NPL * NG * plane_px) * 16u;
+            int rowent[PPX], colx[PPX];
+            bool live[PPX];
+            unsigned ldsoff[PPX], voff[PPX];
+#pragma unroll
+            for (int i = 0; i < PPX; ++i) {
+                const int pc = wave + 4 * i < NPIECE ? wave + 4 * i : NPIECE - 1;  // (past the end: the last piece again -- uniform vmcnt bookkeeping)
+                const int e = pc * 64 + lane;
+                live[i] = e < NENT;
+                const int ee = live[i] ? e : 0;
+                const int plg = ee / (XR * XS), rem = ee - plg * (XR * XS), r = rem / XS, c = rem - r * XS;
+                rowent[i] = (plg * (H + 2) + r) * W;  // (plane, group, tile row) part; plg = plane * NG + group as in the layout
+                colx[i] = c == XS - 1 ? 0 : c - 1;    // (the dump column: any address)
+                ldsoff[i] = (unsigned)pc * 1024u;
+            }
+            int x_item = 0, x_c = 0;
+            const unsigned char* x_base = nullptr;
+            auto set_x_item = [&](int it) __attribute__((always_inline)) {
+                int cot, b, th, tw;
+                decode(it, cot, b, th, tw);
+                x_base = reinterpret_cast<const unsigned char*>(p.x.p0) + (long)b * p.x.bs0 * 4;
+#pragma unroll
+                for (int i = 0; i < PPX; ++i) {
+                    int gc = tw * TW + colx[i];
+                    if (gc < 0) gc += W;
+                    if (gc >= W) gc -= W;  // azimuth is periodic
+                    voff[i] = (unsigned)(rowent[i] + th * TH * W + gc) * 16u;
+                }
+            };
+            auto dma_x = [&](int buf) __attribute__((always_inline)) {  // the cursor's chunk -> x buffer `buf`; advances the cursor
+                const unsigned long long sv = (unsigned long long)(x_base + (size_t)x_c * chunk_bytes);
+                const unsigned char* src = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
+                                                                  (unsigned)__builtin_amdgcn_readfirstlane((int)sv));
+                const unsigned l0 = lds0 + (unsigned)buf * XBYTES;
+#pragma unroll
+                for (int i = 0; i < PPX; ++i)
+                    if (live[i])
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[i]), "s"(src), "s"(l0 + ldsoff[i]) : "memory", "m0");
+                if (x_c + 1 < nchunks)
+                    ++x_c;
+                else if (x_item + 1 < nIt) {
+                    x_c = 0;
+                    set_x_item(++x_item);
+                }  // (past the end: the last chunk again, into the buffer nobody reads)
+            };
+            set_x_item(0);
+            set_dma_item(0);
+            dma_stage(0, ic<0>{});
+            dma_stage(0, ic<1>{});
+            dma_stage(0, ic<2>{});
+            dma_x(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // P
+            asm volatile("" ::: "memory");
+            constexpr int N12 = 2 * PPW + PPX, N3 = 2 * PPW;  // younger operations when the stage due at #1 / #2, at #3 (with x(q+1)) must have landed
+            for (int q = 0; q < Q; ++q) {
+                dma_stage(3 * q, ic<3>{});  // D0: stage 3q+3
+                dma_x((q + 1) & 1);         // x(q+1): its buffer was last read in chunk q-1
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N12) : "memory");  // stage 3q+1 landed
+                __builtin_amdgcn_s_barrier();                               // #1
+                asm volatile("" ::: "memory");
+                dma_stage(3 * q, ic<4>{});  // D1
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N12) : "memory");  // stage 3q+2 landed
+                __builtin_amdgcn_s_barrier();                               // #2
+                asm volatile("" ::: "memory");
+                dma_stage(3 * q, ic<5>{});  // D2
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");   // stage 3q+3 and x(q+1) landed
+                __builtin_amdgcn_s_barrier();                               // #3: publishes x(q+1)
+                asm volatile("" ::: "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing may outlive the block
+            return;
+        }
         // staging unit of this thread: one aligned quad (8 channels x 4 pixels) of one tile row (t4 < 192: interior quads;
         // 192..215: the quad holding a halo column, the three pixels it does not need go to the dump column; 216..255
         // repeat unit 215) -- see conv_bf16x3_stream_kernel
@@ -301,7 +473,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 xpk[eo][0][i2] = xpk[eo][NPLK - 1][i2] = __float_as_uint(qv0);
 #else
                 if constexpr (NPLK == 2) {
-                    split_f16x2(qv0, qv1, xpk[eo][0][i2], xpk[eo][1][i2]);
+                    if constexpr (LSCALED) split_f16x2(qv0, qv1, xpk[eo][0][i2], xpk[eo][1][i2]);
+                    else split_f16x2_true(qv0, qv1, xpk[eo][0][i2], xpk[eo][1][i2]);
                 } else {
                     using f32x2 = __attribute__((ext_vector_type(2))) float;
                     xpk[eo][0][i2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{qv0, qv1}, f16x2));  // v_cvt_pk_f16_f32 (RNE)
@@ -333,55 +506,6 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         u32x4{xpk[eo][pl][0], xpk[eo][pl][1], xpk[eo][pl][2], xpk[eo][pl][3]};
         };
 
-        // ---- weights: LDS-DMA cursor (stage within the tile's co tile; tiles may change co tile) ----
-        // 12 pieces of 1 KiB per stage; stager w issues pieces 3w, 3w+1, 3w+2.  Everything but the lane offset is wave-uniform:
-        // source and LDS base go through SGPRs.
-        const unsigned lane16 = (unsigned)lane * 16;
-        int d_item = 0, d_s = 0;
-        const unsigned char* d_base = nullptr;
-        auto set_dma_item = [&](int it) __attribute__((always_inline)) {
-            int cot, b, th, tw;
-            decode(it, cot, b, th, tw);
-            d_base = wsrc + (size_t)cot * nst * WSTAGE;
-        };
-        // the cursor's stage -> ring slot `slot` (this wave's three pieces); advances the cursor (past the end: the last
-        // stage again -- harmless, keeps the vmcnt bookkeeping uniform)
-        auto dma_stage = [&](int slot) __attribute__((always_inline)) {
-            const unsigned long long sv = (unsigned long long)(d_base + (size_t)d_s * WSTAGE);  // wave-uniform: say so (SGPR operand)
-            const unsigned char* src = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
-                                                              (unsigned)__builtin_amdgcn_readfirstlane((int)sv));
-            if (d_s + 1 < nst)
-                ++d_s;
-            else if (d_item + 1 < nIt) {
-                d_s = 0;
-                set_dma_item(++d_item);
-            }
-#ifdef F2_NO_DMA  // timing ablation (wrong results)
-            if (slot >= 0) return;
-#endif
-            // pieces 3w, 3w+1, 3w+2: one M0 set-up, the instruction offset advances the global and the LDS address together
-            if constexpr (NPLK == 2) {
-                const unsigned char* s3 = src + wave * (PPW * 1024);
-                const unsigned d3 = lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + wave * (PPW * 1024));
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %0, %1\n\t"
-                             "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                             "global_load_lds_dwordx4 %0, %1 offset:2048"
-                             :
-                             : "v"(lane16), "s"(s3), "s"(d3)
-                             : "memory", "m0");
-            } else {  // the h plane only (6 KiB at the start of the stage): pieces w and w + 2
-                const unsigned char* s3 = src + wave * 1024;
-                const unsigned d3 = lds0 + WB0 + (unsigned)((slot & (RING - 1)) * WSTAGE + wave * 1024);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %0, %1\n\t"
-                             "global_load_lds_dwordx4 %0, %1 offset:2048"
-                             :
-                             : "v"(lane16), "s"(s3), "s"(d3)
-                             : "memory", "m0");
-            }
-        };
-
         // ---- prologue: ring stages 0..RING-2 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
         // All 256 blocks start at once and the first pixels are a bandwidth burst (2 chunks x 32 KiB per CU = 16 MiB: 3-4 us of
         // HBM; in-kernel timeline, profiles/r03_launch_overhead.txt), with the multipliers waiting at P.  So: what the first
@@ -401,8 +525,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         }
         table_fetch(0);
         stamp(31);
-#pragma unroll
-        for (int s = 0; s < RING - 1; ++s) dma_stage(s);
+        dma_stage(0, ic<0>{});
+        dma_stage(0, ic<1>{});
+        if constexpr (RING == 4) dma_stage(0, ic<2>{});
         load_next(set1);  // (nchunks >= 4: the cursor stays inside the first tile)
         constexpr int RING_NEWER = (RING - 1) * PPW;
         use_set(set0, ic<RING_NEWER + NL>{});  // (ring stages and chunk 1 are younger)
@@ -430,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
         // stage sigma+RING, due RING-1 barriers later.  One stage is requested per segment, right behind the barrier that frees
         // its slot:  D0(q) = stage 3q+RING-1, D1(q) = 3q+RING, D2(q) = 3q+RING+1.  A stage requested at the start of segment j
-        // must have landed at the end of segment j+RING-2 (STAGE_NEWER younger operations may still fly).
+        // must have landed at the end of segment j+RING-2 (NEWER1..3 younger operations may still fly).
         // The pixels of chunk q+3 are requested in the third segment, into the register set emptied in the first two; they are
         // transformed a whole iteration later (the other set holds chunk q+2 meanwhile).  VMEM queue of one iteration:
         //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw(q+3) [NL] | #3
@@ -438,20 +563,20 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
             const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
             if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
-            dma_stage(3 * q + RING - 1);         // D0
+            dma_stage(3 * q, ic<RING - 1>{});    // D0
             if (q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + PPW) : "memory");  // (only chunk 2 and D0 are younger than chunk 1)
             use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago
             transform_half(cur, 0, nbuf);        // (past the end: the last chunk again, into the buffer nobody reads)
             stamp(10);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+1 landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER1) : "memory");  // stage 3q+1 landed
             stamp(11);
             __builtin_amdgcn_s_barrier();        // #1 = B'_{3q}
             stamp(12);
             asm volatile("" ::: "memory");
-            dma_stage(3 * q + RING);             // D1
+            dma_stage(3 * q, ic<RING>{});        // D1
             transform_half(cur, 1, nbuf);
             stamp(13);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+2 landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER2) : "memory");  // stage 3q+2 landed
             stamp(14);
             __builtin_amdgcn_s_barrier();        // #2 = B'_{3q+1}
             stamp(15);
@@ -461,10 +586,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 ++t_item;
             }
             x_c = last_of_tile ? 0 : x_c + 1;
-            dma_stage(3 * q + RING + 1);         // D2
+            dma_stage(3 * q, ic<RING + 1>{});    // D2
             load_next(cur);                      // pixels of chunk q+3
             stamp(16);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(STAGE_NEWER) : "memory");  // stage 3q+3 landed; this wave's x writes done
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER3) : "memory");  // stage 3q+3 landed; this wave's x writes done
             stamp(17);
             __builtin_amdgcn_s_barrier();        // #3 = B'_{3q+2}: publishes x(q+1)
             stamp(18);
@@ -486,15 +611,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         xb0[n] = lds0 + (unsigned)(((hi * XR + (s >> 1)) * XS + (s & 1) * 32 + l31) * 16);
         xb1[n] = xb0[n] + XBYTES;
     }
-    const unsigned lds_w0 = lds0 + WB0 + (unsigned)((hi * CO_T + l31) * 16);
+    const unsigned lds_w0 = lds0 + WB0 + (unsigned)((hi * COT + l31) * 16);
 
-    f32x16 acc[MR][NR], acl[MR][NR];  // xh wh | xh wl + xl wh (scaled by 2^11)
+    f32x16 acc[MR][NR], acl[ACC2 ? MR : 1][ACC2 ? NR : 1];  // xh wh | xh wl + xl wh (scaled by 2^11); wide tile: all three products in acc
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = acl[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[m][n][r] = 0.f;
+                if constexpr (ACC2) acl[m][n][r] = 0.f;
+            }
 
     // Fragments of one tap: the l plane is used by the first two products only and is single-buffered -- the next tap's is
     // read as soon as its last product has been issued; the h plane is needed up to the last product and is double-buffered.
@@ -505,26 +633,39 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         constexpr int nb = decltype(NB)::value;
         if constexpr (w < MR) {
             u32x4& d = pl == 0 ? fa0[nb][w] : fa1[w];
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(wb), "i"(pl * (3 * NG * CO_T * 16) + tx * (NG * CO_T * 16) + w * 512));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(wb), "i"(pl * (3 * NG * COT * 16) + tx * (NG * COT * 16) + w * 512));
         } else {
             u32x4& d = pl == 0 ? fb0[nb][w - MR] : fb1[w - MR];
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(xb[w - MR]), "i"(pl * (XPL * 16) + ky * (XS * 16) + tx * 16));
         }
     };
-    // all fragments of a tap (0, 0) at once, in the order the taps read them: plane 0, then plane 1
+    // all fragments of a tap (0, 0) at once, in the order the taps read them: plane 0 (into h buffer NB), then plane 1
+    auto frag_all = [&](const unsigned (&xb)[NR], unsigned wb, auto NB) __attribute__((always_inline)) {
+        auto f = [&](auto PL, auto WW) __attribute__((always_inline)) { frag_rd(xb, wb, ic<0>{}, ic<0>{}, PL, WW, NB); };
+        f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{}); f(ic<0>{}, ic<3>{});
+        if constexpr (MR == 4) { f(ic<0>{}, ic<4>{}); f(ic<0>{}, ic<5>{}); }
+        if constexpr (NPLK == 2) {
+            f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
+            if constexpr (MR == 4) { f(ic<1>{}, ic<4>{}); f(ic<1>{}, ic<5>{}); }
+        }
+    };
     auto frag_first = [&](unsigned wb) __attribute__((always_inline)) {
         auto f = [&](auto PL, auto WW) __attribute__((always_inline)) { frag_rd(xb0, wb, ic<0>{}, ic<0>{}, PL, WW, ic<0>{}); };
         f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{}); f(ic<0>{}, ic<3>{});
-        if constexpr (NPLK == 2) { f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{}); }
+        if constexpr (MR == 4) { f(ic<0>{}, ic<4>{}); f(ic<0>{}, ic<5>{}); }
+        if constexpr (NPLK == 2) {
+            f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
+            if constexpr (MR == 4) { f(ic<1>{}, ic<4>{}); f(ic<1>{}, ic<5>{}); }
+        }
     };
 
     int e_c = 0;  // chunk within the current tile
-    // one tap = 12 units: one MFMA + at most one fragment read of the next tap.  T = tap within the chunk, PAR = parity of
+    // one tap = 3 MR NR units (12 / 24): one MFMA + at most one fragment read of the next tap.  T = tap within the chunk, PAR = parity of
     // the chunk (x buffer PAR; tap 8 reads the next chunk's tap 0 from the other x buffer, which the stagers published at
-    // this tap's barrier -- also across a tile boundary).  Products:
-    //   xl wh -> acl | xh wl -> acl | xh wh -> acc        reads behind unit: 0-3 plane h, 4 5 wl' (A), 8 9 xl' (B)
+    // this tap's barrier -- also across a tile boundary).  Products (64-channel tile; the 128-channel tile sends all three to acc):
+    //   xh wl -> acl | xl wh -> acl | xh wh -> acc        reads behind unit: 0 .. MR+NR-1 plane h, MR NR + (0 .. MR-1) wl' (A), 2 MR NR + (0, 1) xl' (B)
     // LDS returns in order, so the waits count younger reads: at the tap's start everything but xl' (2 reads) is needed,
-    // before the second product those too (4 reads of this tap are younger).  A barrier tap waits for everything first:
+    // before the second product those too (the MR + NR reads of this tap are younger).  A barrier tap waits for everything first:
     // its barrier retires a ring slot and, at ky = 2, the x buffer of the previous chunk.
     auto tap = [&](int q, auto TT, auto PAR) __attribute__((always_inline)) {
         constexpr int t = decltype(TT)::value, par = decltype(PAR)::value;
@@ -545,16 +686,17 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one plane: all four fragments of this tap)
         }
-        const unsigned wbn = lds_w0 + (unsigned)(((t < 8 ? sigma + (kyn != ky ? 1 : 0) : sigma + 1) & (RING - 1)) * WSTAGE);
+        // ring slot of the next tap's stage (RING == 3: stage 3 q' + ky' sits in slot ky')
+        const unsigned wbn = RING == 4 ? lds_w0 + (unsigned)(((t < 8 ? sigma + (kyn != ky ? 1 : 0) : sigma + 1) & 3) * WSTAGE) : lds_w0 + (unsigned)(kyn * WSTAGE);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             const int qq = NPLK == 2 ? i / (MR * NR) : 2, m = (i / NR) % MR, n = i % NR;  // (one plane: the xh wh product only)
-            if (i == 4) {
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            if (i == MR * NR) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MR + NR) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            f32x16& ac = qq == 2 ? acc[m][n] : acl[m][n];
+            f32x16& ac = !ACC2 || qq == 2 ? acc[m][n] : acl[ACC2 ? m : 0][ACC2 ? n : 0];
             const u32x4& ua = qq == 0 ? fa1[m] : fa0[cur][m];  // A = weights (rows = output channels), B = pixels
             const u32x4& ub = qq == 1 ? fb1[n] : fb0[cur][n];
             // (unit order: xh(B) wl(A) | xl(B) wh(A) | xh wh -- the A/B roles of "x" and "w" are spelled out in the reads above)
@@ -563,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (i == 0) asm volatile("" :: "v"(fra), "v"(frb), "v"(ac));
             else
 #endif
-            if (t == 0 && c == 0 && (qq == 0 || qq == 2)) {  // first product into each accumulator of a tile: start from zero
+            if (t == 0 && c == 0 && (ACC2 ? (qq == 0 || qq == 2) : i < MR * NR)) {  // first product into each accumulator of a tile: start from zero
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fra, frb, zero, 0, 0, 0);
             } else {
@@ -581,11 +723,23 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (i == 1) fr(ic<0>{}, ic<1>{});
             if (i == 2) fr(ic<0>{}, ic<2>{});
             if (i == 3) fr(ic<0>{}, ic<3>{});
-            if constexpr (NPLK == 2) {
+            if constexpr (MR == 4) {
+                if (i == 4) fr(ic<0>{}, ic<4>{});
+                if (i == 5) fr(ic<0>{}, ic<5>{});
+            }
+            if constexpr (NPLK == 2 && MR == 2) {
                 if (i == 4) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 3)
                 if (i == 5) fr(ic<1>{}, ic<1>{});
                 if (i == 8) fr(ic<1>{}, ic<2>{});  // xl' (its last product was unit 7)
                 if (i == 9) fr(ic<1>{}, ic<3>{});
+            }
+            if constexpr (NPLK == 2 && MR == 4) {
+                if (i == 8) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 7)
+                if (i == 9) fr(ic<1>{}, ic<1>{});
+                if (i == 10) fr(ic<1>{}, ic<2>{});
+                if (i == 11) fr(ic<1>{}, ic<3>{});
+                if (i == 16) fr(ic<1>{}, ic<4>{});  // xl' (its last product was unit 15)
+                if (i == 17) fr(ic<1>{}, ic<5>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -603,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
     using gf4 = f32x4 __attribute__((address_space(1)))*;
     constexpr int SEGW = TW / 32, NQ = MR * NR;
-    static_assert(NQ == 4 && RESQ == 3, "three deferred quarters in the former residual area");
+    static_assert(MRK != 2 || (NQ == 4 && RESQ == 3), "three deferred quarters in the former residual area");
     float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
     f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
     float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
@@ -613,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     const float sc_blk = p.scale ? *(gcf)p.scale : 1.0f;
     const float wsc = p.wscale ? *(gcf)p.wscale : 1.0f;  // inverse of the packer's power-of-two weight scale (exact)
     float* const dump = reinterpret_cast<float*>(smem + RES0) + wave * (RESQ * 1024);
-    float* const patch = reinterpret_cast<float*>(smem + PATCH0) + wave * 256;
+    float* const patch = MRK == 2 ? reinterpret_cast<float*>(smem + PATCH0) + wave * 256 : dump;
     auto fresh_lane = [&]() __attribute__((always_inline)) {  // (per-lane constants must not be hoisted across the MFMA stream)
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -624,7 +778,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
-        const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)(cot * CO_T) * HW);
+        const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)(cot * COT) * HW);
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) rv[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
     };
@@ -643,12 +797,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
-        const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)(cot * CO_T) * HW);
+        const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)(cot * COT) * HW);
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             f32x4 v = t[k8] * wsc + bias_e[m * 4 + k8];
-            if (p.res) v = rv[k8] + v;
-            v *= sc_blk;  // (1.0f without p.scale: exact)
+            v = rv[k8] + v;  // (without a residual the buffers stay zero -- res_request_to returns before it writes them: no select per element)
+            v *= sc_blk;     // (1.0f without p.scale: exact)
             (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
             if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);
@@ -664,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             st_s[k8] = (double)s0[k8] + (double)s1[k8];
             st_q[k8] = (double)q0[k8] + (double)q1[k8];
         }
-        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * CO_T + decltype(M)::value * 32, wave, ln);
+        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * COT + decltype(M)::value * 32, wave, ln);
     };
     auto range_flush = [&](int ln) __attribute__((always_inline)) {
         if (!p.range) return;
@@ -701,10 +855,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         if constexpr (decltype(PAR)::value == 1) {
             if (e_c == nchunks - 1) {  // the tile's last chunk: its biases and the first quarter's residual are requested now
                 const int ln = fresh_lane();
+                if constexpr (MRK == 2) {  // (the wide tile has no registers to hold 16 biases through a chunk: requested at the tile's end)
 #pragma unroll
-                for (int m = 0; m < MR; ++m)
+                    for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = ((gcf)p.bias)[e_cot * CO_T + m * 32 + k8 * 8 + (ln >> 3)];
+                        for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = ((gcf)p.bias)[e_cot * COT + m * 32 + k8 * 8 + (ln >> 3)];
+                }
                 res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
             }
         }
@@ -712,6 +868,119 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         tap(q, ic<3>{}, PAR); tap(q, ic<4>{}, PAR); tap(q, ic<5>{}, PAR);
         tap(q, ic<6>{}, PAR); tap(q, ic<7>{}, PAR); tap(q, ic<8>{}, PAR);
         ++e_c;
+        if constexpr (MRK == 4) {
+            // ---- 128-channel tile: ONE accumulator per MFMA tile, eight quarters (m, n) per wave.  Six are finished at the tile's end, the
+            // last row block's two (6, 7) wait, turned, in 32 KiB of LDS and are finished behind the next tile's first two chunks (the
+            // multipliers bound a chunk of this tile -- 24 MFMAs per tap -- so a deferred quarter costs what it takes; at the tile's end all
+            // four stagers and the matrix pipe wait).  Biases are requested at the tile's end, one row block ahead (the loop has no
+            // registers for sixteen of them: as 16 loads in the last chunk they were spilled one by one behind vmcnt(0) -- 4.5 k cycles);
+            // the residual of quarters 1 .. 3 (HBM: ~2 k cycles) is requested up front and a quarter's buffer takes the quarter four
+            // further on as soon as it is free -- with one quarter of lead every quarter waited for its residual (17.7 k cycles per tile end).
+            // the waiting row block (quarters 6, 7): both behind the next tile's FIRST chunk -- quarter 6's residual was requested at the
+            // tile's end, quarter 7's is requested here and has quarter 6's ~1.5 k cycles to arrive; nothing but that residual and four
+            // biases stays alive through a chunk (a statistics carry between two slices was spilled and re-read behind vmcnt(0))
+            auto slice_w = [&](const f32x4 (&rv6)[4], f32x4 (&rv7)[4], auto REQ) __attribute__((always_inline)) {
+                const int ln = fresh_lane();
+                if constexpr (decltype(REQ)::value) res_request_to(rv7, ic<7>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
+                float ps0[4], pq0[4], ps1[4], pq1[4];
+                {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
+                    quarter(ic<6>{}, t, rv6, pe_b, pe_th, pe_tw, pe_cot, ln, ps0, pq0);
+                }
+                {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + 1024 + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
+                    quarter(ic<7>{}, t, rv7, pe_b, pe_th, pe_tw, pe_cot, ln, ps1, pq1);
+                }
+                half_stats(ic<3>{}, ps0, pq0, ps1, pq1, pe_b, pe_th, pe_tw, pe_cot, ln);
+                range_flush(ln);
+                pending = false;
+            };
+            if constexpr (decltype(PAR)::value == 0) {
+                if (pending && e_c == 1) {
+                    // the next chunk's first fragments (72 registers, prefetched by tap 8) are dropped for the slice and read again behind
+                    // it: with them alive the slice spilled fragments around itself
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("" : "=v"(fa0[1][0]), "=v"(fa0[1][1]), "=v"(fa0[1][2]), "=v"(fa0[1][3]), "=v"(fb0[1][0]), "=v"(fb0[1][1]));
+                    asm volatile("" : "=v"(fa1[0]), "=v"(fa1[1]), "=v"(fa1[2]), "=v"(fa1[3]), "=v"(fb1[0]), "=v"(fb1[1]));
+                    f32x4 rv7[4] = {};
+                    slice_w(rv_e, rv7, ic<1>{});
+                    frag_all(xb1, lds_w0, ic<1>{});  // (chunk q + 1: x buffer 1, stage 3 (q + 1) in ring slot 0, h buffer 1)
+                }
+            } else {
+                if (e_c == nchunks) {
+                    e_c = 0;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
+                    stamp(7);
+                    const int ln = fresh_lane();
+                    const int l31e = ln & 31, hie = ln >> 5;
+                    const bool last_tile = e_item + 1 == nIt;
+                    auto bias_request = [&](auto M) __attribute__((always_inline)) {
+                        constexpr int m = decltype(M)::value;
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = ((gcf)p.bias)[e_cot * COT + m * 32 + k8 * 8 + (ln >> 3)];
+                    };
+                    bias_request(ic<0>{});
+                    bias_request(ic<1>{});
+                    f32x4 rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
+                    res_request_to(rv1, ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
+                    res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
+                    res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                    auto do_q = [&](auto QD, f32x4 (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+                        constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
+                        f32x4 t[4];
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) patch[(j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
+                            t[k8] = *reinterpret_cast<const f32x4*>(patch + (ln >> 3) * 32 + (ln & 7) * 4);
+                        }
+                        quarter(QD, t, rv, e_b, e_th, e_tw, e_cot, ln, ps, pq);
+                    };
+                    float ps0[4], pq0[4], ps1[4], pq1[4];
+                    stamp(20);
+                    do_q(ic<0>{}, rv_e, ps0, pq0);
+                    stamp(21);
+                    res_request_to(rv_e, ic<4>{}, e_b, e_th, e_tw, e_cot, ln);
+                    do_q(ic<1>{}, rv1, ps1, pq1);
+                    stamp(22);
+                    res_request_to(rv1, ic<5>{}, e_b, e_th, e_tw, e_cot, ln);
+                    half_stats(ic<0>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    stamp(23);
+                    bias_request(ic<2>{});
+                    do_q(ic<2>{}, rv2, ps0, pq0);
+                    stamp(24);
+                    if (last_tile) res_request_to(rv2, ic<6>{}, e_b, e_th, e_tw, e_cot, ln);  // (nothing left to hide the waiting quarters behind)
+                    do_q(ic<3>{}, rv3, ps1, pq1);
+                    if (last_tile) res_request_to(rv3, ic<7>{}, e_b, e_th, e_tw, e_cot, ln);
+                    half_stats(ic<1>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    bias_request(ic<3>{});
+                    do_q(ic<4>{}, rv_e, ps0, pq0);
+                    do_q(ic<5>{}, rv1, ps1, pq1);
+                    half_stats(ic<2>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    // the last row block waits in LDS (the patch -- the first KiB of slot 0 -- is free now: LDS operations of a wave are in order)
+                    turn_write(ic<6>{}, dump, ln);
+                    turn_write(ic<7>{}, dump + 1024, ln);
+                    pe_b = e_b; pe_th = e_th; pe_tw = e_tw; pe_cot = e_cot;
+                    pending = true;
+                    stamp(8);
+                    if (last_tile) {
+                        slice_w(rv2, rv3, ic<0>{});  // (clears `pending`)
+                        stamp(43);
+                    } else {
+                        res_request(ic<6>{}, e_b, e_th, e_tw, e_cot, ln);
+                    }
+                    // (the accumulators restart from C = 0 in the next tile's first products: end the old values' lives)
+                    asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
+                    asm volatile("" : "=v"(acc[2][0]), "=v"(acc[2][1]), "=v"(acc[3][0]), "=v"(acc[3][1]));
+                    if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
+                    frag_first(lds_w0);  // (stage 3 (q + 1): ring slot 0)
+                }
+            }
+        } else {
         if constexpr (decltype(PAR)::value == 0) {
             if (pending && e_c == 1) slice(ic<1>{});
             if (pending && e_c == 3) slice(ic<3>{});
@@ -776,6 +1045,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 frag_first(lds_w0 + (unsigned)(((3 * (q + 1)) & (RING - 1)) * WSTAGE));
             }
         }
+        }
     };
 
     stamp(36);
@@ -791,13 +1061,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     stamp_real(1);
 }
 
-// ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane h / l][tap in row][group][co 64][8 ch] f16 ----
+// ---- weight packing: OIHW fp32 -> [co tile][chunk][kernel row][plane h / l][tap in row][group][co 64 | 128][8 ch] f16 ----
+// cot = output channels per tile (64 | 128); lscaled: the l plane is 2^11 (w - h) (two-accumulator kernel) or w - h at its true scale
+// (the 128-channel tile's single accumulator; the layer's power-of-two scale keeps it out of the fp16 subnormals for every weight
+// within 2^-12 of the largest)
 // range[0] is raised to 1 if a weight does not fit the fp16 range (|w| >= 65504); the packed value saturates.
 // wscale (may be nullptr: unscaled): [0] = float bits of max|w| (launch_weight_absmax), [1] <- the inverse of the power-of-two
 // scale s applied to every weight of the layer (f16x2_weight_scale: max|w| s in [2^9, 2^10); the kernel's epilogue multiplies
 // the matrix product by it -- exact)
 __global__ void pack_conv_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout, int Cin,
-                                       long total, int* __restrict__ range, float* __restrict__ wscale) {
+                                       long total, int* __restrict__ range, float* __restrict__ wscale, int cot_size, int lscaled) {
     using namespace f2;
     __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL
     float inv = 1.0f;
@@ -808,8 +1081,8 @@ __global__ void pack_conv_f16x2_kernel(const float* __restrict__ w, unsigned sho
         long r = i;
         const int ch = r % 8;
         r /= 8;
-        const int col = r % CO_T;
-        r /= CO_T;
+        const int col = r % cot_size;
+        r /= cot_size;
         const int g = r % NG;
         r /= NG;
         const int tx = r % 3;
@@ -820,11 +1093,12 @@ __global__ void pack_conv_f16x2_kernel(const float* __restrict__ w, unsigned sho
         r /= 3;
         const int c = r % nchunks;
         const int cot = r / nchunks;
-        const int co = cot * CO_T + col, ci = c * CK + g * 8 + ch;
+        const int co = cot * cot_size + col, ci = c * CK + g * 8 + ch;
         const float v = w[((long)co * Cin + ci) * 9 + ky * 3 + tx] * ws;
         if (!(fabsf(v) < 65504.f) && range) atomicOr(range, 1);  // (scaled: only a non-finite weight gets here)
         unsigned ph, pq;
-        split_f16x2(v, v, ph, pq);
+        if (lscaled) split_f16x2(v, v, ph, pq);
+        else split_f16x2_true(v, v, ph, pq);
         dst[i] = (unsigned short)((pl == 0 ? ph : pq) & 0xffffu);
     }
 }
@@ -839,14 +1113,23 @@ static int f2_cu_count() {
     return v;
 }
 
-// 3x3, whole 4 x 64 pixel tiles (the wide epilogue has no pixel predication), 64-channel output tiles, 64 <= Cin <= 512 in
+// 3x3, whole 4 x 64 pixel tiles (the wide epilogue has no pixel predication), 64- (or 128-) channel output tiles, 64 <= Cin <= 512 in
 // multiples of 64 (an even number of 16-channel chunks, at least four; the (a, d) table), a concat seam on a chunk boundary.
-bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W) {
-    return taps == 9 && Cout % f2::CO_T == 0 && Cin % (4 * f2::CK) == 0 && Cin * 8 <= f2::ADTAB_BYTES && H % f2::TH == 0 &&
-           W % f2::TW == 0 && H * (long)W * 16 < (1L << 31);
+bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile) {
+    return taps == 9 && (co_tile == 64 || co_tile == 128) && Cout % co_tile == 0 && Cin % (4 * f2::CK) == 0 && Cin * 8 <= f2::ADTAB_BYTES &&
+           H % f2::TH == 0 && W % f2::TW == 0 && H * (long)W * 16 < (1L << 31);
 }
 
 long conv_f16x2_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * f2::NPL / 2; }
+
+int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch) {
+    const bool wide_ok = conv_f16x2_supported(Cin, Cout, 9, H, W, 128);
+    if (const char* e = getenv("R2DM_F2_CO_TILE")) return atoi(e) == 128 && wide_ok ? 128 : 64;  // (read per call: per-kernel tests switch it)
+    // The one-accumulator tile takes three truncating accumulator updates per tap where the 64-channel tile takes one: its rms error
+    // stays below the fp32-MFMA kernel's (an exact fmaf chain, two-level above 128 channels) up to Cin = 128 (K = 1152) -- measured in
+    // tests/test_hip_kernels.py::test_conv3x3_both_operand_splits -- and is 1.2x / 1.7x of it at Cin = 256 / 512: not used there
+    return wide_ok && Cin <= 128 && (pixels_times_batch / (f2::TH * f2::TW)) * (Cout / 128) >= f2_cu_count() ? 128 : 64;
+}
 
 // max_bits <- float bits of max|w[0 .. n)| (non-negative floats order like their bit patterns; NaN sorts above infinity)
 __global__ void weight_absmax_kernel(const float* __restrict__ w, long n, int* __restrict__ max_bits) {
@@ -870,58 +1153,65 @@ hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale) {
+hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale, int co_tile) {
+    if ((co_tile != 64 && co_tile != 128) || Cout % co_tile) return hipErrorInvalidValue;
     const long total = (long)Cout * Cin * 9 * f2::NPL;
     if (wscale) {
         hipError_t e = launch_weight_absmax(w, (long)Cout * Cin * 9, reinterpret_cast<int*>(wscale), s);
         if (e != hipSuccess) return e;
     }
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale);
+    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale, co_tile, co_tile == 64);
     return hipGetLastError();
 }
 
-template <int PRO, int NPLK>
+template <int PRO, int NPLK, int MRK>
 static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
-    auto kern = conv_f16x2_kernel<PRO, NPLK>;
+    auto kern = conv_f16x2_kernel<PRO, NPLK, MRK>;
+    constexpr int LDS_TOTAL = f2::Geo<MRK>::LDS_TOTAL, COT = f2::Geo<MRK>::COT;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_TOTAL);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     static const bool one_tile_blocks = getenv("R2DM_F2_NONPERSISTENT") != nullptr;  // experiments: one tile per block
     const int n_cu = f2_cu_count();
     const unsigned grid = (unsigned)(tiles < n_cu || one_tile_blocks ? tiles : n_cu);
-    const int nCoT = p.Cout / f2::CO_T, nTw = p.W / f2::TW, nTh = p.H / f2::TH;
+    const int nCoT = p.Cout / COT, nTw = p.W / f2::TW, nTh = p.H / f2::TH;
     const int dmax = nCoT > nTw ? (nCoT > nTh ? nCoT : nTh) : (nTw > nTh ? nTw : nTh);
     if (tiles * dmax >= (1ll << 32)) return hipErrorInvalidValue;  // (F2Div is exact below that)
     const F2Div dv{f2_magic(nCoT), f2_magic(nTw), f2_magic(nTh)};
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2::LDS_TOTAL, s, p, (int)tiles, dv);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_TOTAL, s, p, (int)tiles, dv);
     return hipGetLastError();
 }
 
+template <int MRK>
+static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
+    const long tiles = (long)(p.Cout / f2::Geo<MRK>::COT) * (p.W / f2::TW) * (p.H / f2::TH) * p.B;
+    if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
+        switch (p.prologue) {
+            case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK>(p, tiles, s);
+            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 1, MRK>(p, tiles, s);
+            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 1, MRK>(p, tiles, s);
+        }
+    }
+    switch (p.prologue) {
+        case PRO_NONE: return launch_f2<PRO_NONE, 2, MRK>(p, tiles, s);
+        case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2, MRK>(p, tiles, s);
+        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2, MRK>(p, tiles, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
-    if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W) || p.co_tile != 64) return hipErrorInvalidValue;
+    if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile)) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
 #ifndef F2_PROF
     if (p.prof != nullptr) return hipErrorInvalidValue;
 #endif
-    const long tiles = (long)(p.Cout / f2::CO_T) * (p.W / f2::TW) * (p.H / f2::TH) * p.B;
-    if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
-        switch (p.prologue) {
-            case PRO_NONE: return launch_f2<PRO_NONE, 1>(p, tiles, s);
-            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 1>(p, tiles, s);
-            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 1>(p, tiles, s);
-        }
-    }
-    switch (p.prologue) {
-        case PRO_NONE: return launch_f2<PRO_NONE, 2>(p, tiles, s);
-        case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2>(p, tiles, s);
-        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2>(p, tiles, s);
-    }
-    return hipErrorInvalidValue;
+    return p.co_tile == 128 ? launch_f2_tile<4>(p, s) : launch_f2_tile<2>(p, s);
 }
 
 }  // namespace r2dm

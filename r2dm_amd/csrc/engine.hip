@@ -39,6 +39,8 @@ int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+static const bool g_debug_sync = getenv("R2DM_DEBUG_SYNC") != nullptr;  // fault hunting: wait for and name every launch (read once)
+
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
 
@@ -50,6 +52,7 @@ struct ConvLayer {
     // second packing of the same weights for ALGO_F16X2 (conv_f16x2.hip): the residual blocks' 3x3 convolutions, whose
     // input is GroupNorm-normalised; selected per launch by the handle's precision mode (r2dm_set_conv_pieces)
     bool f2 = false;
+    int f2_cot = 64;  // output channels per tile of that packing: 64 (two accumulators) or 128 (one; conv_f16x2_pick_co_tile)
     size_t w_f2 = 0, ws_f2 = 0;  // ws_*: two floats -- [0] max|w| (packer scratch), [1] inverse of the packer's power-of-two weight scale
     // ... and for ALGO_P1F16 (proj_f16x2.hip): the 1x1 projections of the attention block
     bool p1 = false;
@@ -178,6 +181,7 @@ struct r2dm_handle {
         }();
         if (L.algo == ALGO_BF16X3 && H > 0 && conv_f16x2_supported(cin, cout, L.taps, H, W) && (px_batch / 256) * (cout / 64) >= f2_min_tiles) {
             L.f2 = true;
+            L.f2_cot = conv_f16x2_pick_co_tile(cin, cout, H, W, px_batch);
             L.w_f2 = take((size_t)conv_f16x2_packed_floats(cin, cout));
             L.ws_f2 = take(2);
         }
@@ -376,7 +380,7 @@ struct Ctx {
 
     bool dry() const { return ar->dry; }
     void note(hipError_t e, const char* w) {
-        static const bool debug_sync = getenv("R2DM_DEBUG_SYNC") != nullptr;  // fault hunting: wait for and name every launch
+        const bool debug_sync = g_debug_sync;  // fault hunting: wait for and name every launch
         if (debug_sync && e == hipSuccess && !dry()) {
             fprintf(stderr, "[r2dm] %s ...", w);
             fflush(stderr);
@@ -502,7 +506,7 @@ struct Ctx {
                 p.algo = ALGO_F16X2;
                 p.w = blob(L.w_f2);
                 p.wscale = blob(L.ws_f2) + 1;
-                p.co_tile = 64;
+                p.co_tile = L.f2_cot;
                 p.pieces = h->conv_pieces;
             }
             if (L.p1 && h->f16_path() && pro != PRO_AFFINE_SILU && (pro != PRO_NONE || input_bounded)) {
@@ -543,7 +547,7 @@ struct Ctx {
                     (void)hipEventRecord(e0, st);
                 }
             }
-            if (getenv("R2DM_DEBUG_SYNC"))
+            if (g_debug_sync)
                 fprintf(stderr, "[r2dm] conv algo %d %d->%d taps %d co_tile %d %dx%d B %d pro %d x %p/%p (c0 %d) y %p res %p aff %p stat %p ws [%p, +%zu)\n", p.algo, p.Cin,
                         p.Cout, p.taps, p.co_tile, H, W, B, pro, (const void*)p.x.p0, (const void*)p.x.p1, p.x.c0, (void*)p.y, (const void*)p.res, (const void*)p.aff,
                         (void*)p.stat, (void*)ar->base, ar->cap);
@@ -865,7 +869,7 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
                                  s.conv.cin_pad, st, s.conv.algo, s.conv.src_cin, s.conv.src_off));
         if (s.conv.f2)
             HIP_TRY(launch_pack_conv_f16x2(src, h->blob + s.conv.w_f2, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st,
-                                           h->blob + s.conv.ws_f2));
+                                           h->blob + s.conv.ws_f2, s.conv.f2_cot));
         if (s.conv.p1)
             HIP_TRY(launch_pack_proj_f16x2(src, h->blob + s.conv.w_p1, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st,
                                            h->blob + s.conv.ws_p1));
@@ -922,14 +926,24 @@ int r2dm_q_step(const float* x_s, const float* noise, const float* coef, float* 
 
 int r2dm_lidar_postprocess(const float* x, const float* ang, float* out, int32_t B, int32_t H, int32_t W,
                            float min_depth, float max_depth, void* stream) {
+    return r2dm_lidar_postprocess_fmt(x, ang, out, B, H, W, min_depth, max_depth, 0, stream);
+}
+
+int r2dm_lidar_postprocess_fmt(const float* x, const float* ang, float* out, int32_t B, int32_t H, int32_t W,
+                               float min_depth, float max_depth, int32_t depth_format, void* stream) {
     if (!x || !ang || !out) return fail(1, "null argument");
-    HIP_TRY(launch_lidar_postprocess(x, ang, out, B, H, W, min_depth, max_depth, (hipStream_t)stream));
+    if (depth_format < 0 || depth_format > 2) return fail(1, "depth_format must be 0 (log_depth), 1 (inverse_depth) or 2 (depth)");
+    HIP_TRY(launch_lidar_postprocess(x, ang, out, B, H, W, min_depth, max_depth, (hipStream_t)stream, depth_format));
     return 0;
 }
 
 static int g_single_kernel_pieces = 2;  // r2dm_conv2d_ring (per-op tests)
 
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces) {
+    if (!h && pieces == 4) {  // per-op tests only: the fp32-input MFMA (an exact fmaf chain) as the yardstick of the split-operand kernels
+        g_single_kernel_pieces = 4;
+        return 0;
+    }
     if (pieces < 1 || pieces > 3)
         return fail(1, "pieces must be 2 (fp16 + scaled fp16 residual: the default parity mode), 3 (three bf16 pieces: fp32 operand range) or "
                        "1 (one fp16 product per MAC: reduced precision)");
@@ -1010,17 +1024,19 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.taps = ksize * ksize;
     p.pieces = 3;
     p.algo = conv_pick_algo(cin, cout, p.taps);
-    if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale)) p.algo = ALGO_F32;  // plain convolutions only
+    if (g_single_kernel_pieces == 4 && p.algo != ALGO_DIRECT) p.algo = ALGO_F32;  // (test hook: the fp32-input MFMA kernel)
+    if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale || W % 4 != 0)) p.algo = ALGO_F32;  // plain convolutions of 16-byte rows only
+                                                                                                             // (any other width runs on the fp32-MFMA kernel)
     // per-op tests: with pieces = 2 every shape the f16x2 kernel covers goes there (the engine restricts it to normalised inputs)
     if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces != 3 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
-    if (p.algo == ALGO_F32 && g_single_kernel_pieces != 3 && prologue != PRO_AFFINE_SILU && proj_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_P1F16;
+    if (p.algo == ALGO_F32 && g_single_kernel_pieces < 3 && prologue != PRO_AFFINE_SILU && proj_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_P1F16;
     if (p.algo == ALGO_F16X2 || p.algo == ALGO_P1F16) p.pieces = g_single_kernel_pieces;
-    p.co_tile = (p.algo == ALGO_F16X2 || p.algo == ALGO_P1F16) ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    p.co_tile = p.algo == ALGO_F16X2 ? conv_f16x2_pick_co_tile(cin, cout, H, W, (long)B * H * W) : p.algo == ALGO_P1F16 ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
     p.CinPad = p.algo != ALGO_F32 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
     if (p.algo == ALGO_F16X2) {  // the range flag and the weight scale: behind the packed weights (r2dm_conv_packed_elems reserves 64 floats)
         float* tail = w_packed + conv_f16x2_packed_floats(cin, cout);
         HIP_TRY(hipMemsetAsync(tail, 0, sizeof(int), st));
-        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, (int*)tail, st, tail + 2));
+        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, (int*)tail, st, tail + 2, p.co_tile));
         p.wscale = tail + 3;
     } else if (p.algo == ALGO_P1F16) {
         float* tail = w_packed + proj_f16x2_packed_floats(cin, cout);
@@ -1082,7 +1098,7 @@ int r2dm_fir_up2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int3
 
 int r2dm_attention(const float* qkv, float* out, int32_t B, int32_t C, int32_t heads, int32_t N, void* stream) {
     if (!attention_supported(C, heads, N)) return fail(1, "attention: unsupported shape C=%d heads=%d N=%d", C, heads, N);
-    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream, g_single_kernel_pieces == 3 ? 0 : g_single_kernel_pieces));  // (per-op tests cover all three)
+    HIP_TRY(launch_attention(qkv, out, B, C, heads, N, (hipStream_t)stream, g_single_kernel_pieces >= 3 ? 0 : g_single_kernel_pieces));  // (per-op tests cover all three)
     return 0;
 }
 

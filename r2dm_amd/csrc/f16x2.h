@@ -49,4 +49,16 @@ __device__ __forceinline__ void split_f16x2(float v0, float v1, unsigned& ph, un
     pl = __builtin_bit_cast(unsigned, l);
 }
 
+// the same split with the residual at its TRUE scale, l = RNE_f16(v - h): what a single accumulator needs (all three products
+// of x w = xh wh + xh wl + xl wh + O(2^-22) on one scale).  l leaves the fp16 normals below |v| ~ 2^-3 and is then exact to 2^-25
+// absolute: O(1) activations keep ~2^-25 of absolute precision (fp32: 2^-24 relative), weights are pre-scaled per layer
+__device__ __forceinline__ void split_f16x2_true(float v0, float v1, unsigned& ph, unsigned& pl) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);
+    const float r0 = v0 - (float)h[0], r1 = v1 - (float)h[1];  // exact
+    const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+    ph = __builtin_bit_cast(unsigned, h);
+    pl = __builtin_bit_cast(unsigned, l);
+}
+
 }  // namespace r2dm

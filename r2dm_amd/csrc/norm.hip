@@ -161,7 +161,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         // with the fp16 limit by r2dm_check_range)
         if (range_flag) {
             const float d = sh - mean * a;
-            const float bound = fabsf(a) * gmax + fabsf(d);
+            // ... or, where that one is looser (a near-constant group: large |mean| / sigma makes |a| M and |d| both huge although
+            // they cancel), the worst-case bound on a normalised value, |x_hat| <= sqrt(n - 1) (Samuelson): |w| sqrt(n) + |sh|.
+            // Both are rigorous; the smaller one is recorded (never looser than round 2's guard)
+            const float data_bound = fabsf(a) * gmax + fabsf(d);
+            const float worst_bound = (fabsf(w) * (float)sqrt(n) + fabsf(sh)) * 1.000001f;
+            const float bound = data_bound > worst_bound ? worst_bound : data_bound;  // (a NaN data bound stays: the comparison is false)
             atomicMax(range_flag + 1, __float_as_int(bound));
         }
     }

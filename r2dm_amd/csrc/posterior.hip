@@ -105,9 +105,11 @@ hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s) {
 }
 
 // ---- LiDAR post-processing ("next" row f.1) ------------------------------------------------
-// sample (B,2,H,W) in [-1,1] -> (B,5,H,W): metric depth (log-depth decoding, masked to
+// sample (B,2,H,W) in [-1,1] -> (B,5,H,W): metric depth (decoded by the checkpoint's depth format, masked to
 // (min_depth, max_depth)), Cartesian x,y,z along the per-pixel ray angles, reflectance in [0,1].
-// /root/reference/utils/lidar.py:49-61,98-120 ; /root/reference/sample_and_save.py:52-57.
+// /root/reference/utils/lidar.py:49-61,95-120 ; /root/reference/sample_and_save.py:52-57.
+// FMT: 0 log_depth  metric = exp2(d log2(max + 1)) - 1 | 1 inverse_depth  metric = (1 / (d + 1e-8)) min | 2 depth  metric = d max
+template <int FMT>
 __global__ __launch_bounds__(256) void lidar_post_kernel(const float* __restrict__ x, const float* __restrict__ ang,
                                                          float* __restrict__ y, long hw, float min_d, float max_d,
                                                          float log2_range) {
@@ -116,7 +118,10 @@ __global__ __launch_bounds__(256) void lidar_post_kernel(const float* __restrict
     float* yb = y + (long)b * 5 * hw;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
         const float d = (xb[i] + 1.0f) / 2.0f, r = (xb[hw + i] + 1.0f) / 2.0f;
-        float metric = exp2f(d * log2_range) - 1.0f;
+        float metric;
+        if (FMT == 0) metric = exp2f(d * log2_range) - 1.0f;
+        else if (FMT == 1) metric = __fmul_rn(__frcp_rn(d + 1e-8f), min_d);  // (torch evaluates `scalar / tensor` as tensor.reciprocal() * scalar: two roundings)
+        else metric = d * max_d;
         const float m = (metric > min_d && metric < max_d) ? 1.0f : 0.0f;
         metric = metric * m;
         const float m2 = (metric > min_d && metric < max_d) ? 1.0f : 0.0f;
@@ -131,12 +136,18 @@ __global__ __launch_bounds__(256) void lidar_post_kernel(const float* __restrict
 }
 
 hipError_t launch_lidar_postprocess(const float* x, const float* angles, float* y, int B, int H, int W, float min_d,
-                                    float max_d, hipStream_t s) {
+                                    float max_d, hipStream_t s, int depth_format) {
     const long hw = (long)H * W;
     long bx = (hw + 255) / 256;
     if (bx > 1024) bx = 1024;
-    lidar_post_kernel<<<dim3((unsigned)bx, B), 256, 0, s>>>(x, angles, y, hw, min_d, max_d,
-                                                          (float)log2((double)max_d + 1.0));
+    const dim3 grid((unsigned)bx, B);
+    const float l2 = (float)log2((double)max_d + 1.0);
+    switch (depth_format) {
+        case 0: lidar_post_kernel<0><<<grid, 256, 0, s>>>(x, angles, y, hw, min_d, max_d, l2); break;
+        case 1: lidar_post_kernel<1><<<grid, 256, 0, s>>>(x, angles, y, hw, min_d, max_d, l2); break;
+        case 2: lidar_post_kernel<2><<<grid, 256, 0, s>>>(x, angles, y, hw, min_d, max_d, l2); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

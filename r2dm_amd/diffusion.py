@@ -53,11 +53,18 @@ def _range_guard(model):
     return guard() if callable(guard) else contextlib.nullcontext()
 
 
-def _early_range_check(model):
-    """One synchronising range check after the first denoiser call of a long loop (one sync per ``sample`` call)."""
-    check = getattr(model, "check_range", None)
-    if callable(check):
-        check()
+def _early_range_check(model, num_steps: int) -> bool:
+    """One synchronising range check after the first denoiser call of a loop (one sync per ``sample`` call).  True = the guard
+    tripped and the denoiser switched itself to the wide-range operand split (EfficientUNet.check_range_or_fall_back): the
+    caller repeats that call.  With ``strict_range`` a tripped guard raises, and short loops (<= 8 steps) skip the early
+    check -- the deferred one at the loop's end reports it."""
+    model = getattr(model, "_orig_mod", model)  # (torch.compile wrapper)
+    check = getattr(model, "check_range_or_fall_back", None)
+    if not callable(check):
+        return False
+    if getattr(model, "strict_range", False) and num_steps <= 8:
+        return False
+    return check()
 
 
 def _log(t: torch.Tensor, eps: float = 1e-20) -> torch.Tensor:
@@ -310,21 +317,16 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         return torch.cat(conds), torch.stack(rows).contiguous(), (_M_CT_DDPM if mode == "ddpm" else _M_CT_DDIM)
 
     def _sample_tables(self, num_steps: int, batch_size: int, mode: str, ddim_eta: float, dev):
-        """(cond (S, B), coef (S, B, 8), kernel mode) of a whole ``sample`` call on the device.  The table is a pure function of
-        the schedule and the step count; evaluating it row by row on the host (see ``_coefficients``) costs ~40 ms for 256
-        steps with the GPU idle, so the last few are kept (the reference recomputes its scalars inside every step)."""
-        key = (num_steps, batch_size, mode, float(ddim_eta), str(dev), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high)
-        cache = self.__dict__.setdefault("_tables", {})
-        hit = cache.get(key)
-        if hit is None:
-            steps = torch.linspace(1.0, 0.0, num_steps + 1)
-            cond, coef, mode_id = self._coefficients(steps[:-1], steps[1:], mode, ddim_eta)
-            cond = cond[:, None].expand(num_steps, batch_size).contiguous().to(dev)
-            coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
-            if len(cache) >= 8:
-                cache.pop(next(iter(cache)))
-            hit = cache[key] = (cond, coef, mode_id)
-        return hit
+        """(cond (S, B), coef (S, B, 8), kernel mode) of a whole ``sample`` call on the device: ``_table_rows`` walked to its
+        end (ONE implementation builds, caches and evicts the tables -- the one ``sample`` uses)."""
+        row, mode_id = self._table_rows(num_steps, batch_size, mode, ddim_eta, dev)
+        for i in range(num_steps):
+            row(i)
+        cond, coef, _ = self.__dict__["_tables"][self._table_key(num_steps, batch_size, mode, ddim_eta, dev)]
+        return cond, coef, mode_id
+
+    def _table_key(self, num_steps, batch_size, mode, ddim_eta, dev):
+        return (num_steps, batch_size, mode, float(ddim_eta), str(torch.device(dev)), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high)
 
     def _table_rows(self, num_steps: int, batch_size: int, mode: str, ddim_eta: float, dev):
         """``row(i) -> (cond (B,), coef (B, 8))`` and ``mode_id`` for a ``sample`` call.  A cached table is indexed; a new one is
@@ -334,7 +336,7 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         step.  Rows travel through pinned host memory (an asynchronous copy on the sampling stream: the host never waits for the
         GPU) into the device table, which enters the cache when its last row is in."""
         dev = torch.device(dev)
-        key = (num_steps, batch_size, mode, float(ddim_eta), str(dev), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high)
+        key = self._table_key(num_steps, batch_size, mode, ddim_eta, dev)
         cache = self.__dict__.setdefault("_tables", {})
         hit = cache.get(key)
         if hit is not None:
@@ -366,12 +368,15 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
 
     @torch.inference_mode()
     def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",
-               ddim_eta: float = 0.0):
-        """One reverse step p(z_s | z_t), 0 <= s < t <= 1 (continuous_time.py:192-232)."""
+               ddim_eta: float = 0.0, _early_check: int = 0):
+        """One reverse step p(z_s | z_t), 0 <= s < t <= 1 (continuous_time.py:192-232).
+        (``_early_check``: internal -- the first step of a loop under the deferred range guard passes its step count.)"""
         self._objective_id()
         cond, coef, mode_id = self._coefficients(step_t, step_s, mode, ddim_eta)
         dev = x_t.device
         prediction = self.model(x_t, cond.to(dev))
+        if _early_check and _early_range_check(self.model, _early_check):
+            prediction = self.model(x_t, cond.to(dev))  # (repeated on the wide-range operand split)
         noise = self.randn_like(x_t, rng=rng)
         return self._posterior(x_t, prediction, noise, coef.to(dev), mode_id)
 
@@ -390,8 +395,8 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
                 cond_i, coef_i = row(i)
                 noise, drawn = self._randn_like_ahead(x, rng=rng)
                 prediction = self.model(x, cond_i)
-                if i == 0 and num_steps > 8:
-                    _early_range_check(self.model)  # a checkpoint the fp16 operand path cannot run fails now, not after the loop
+                if i == 0 and _early_range_check(self.model, num_steps):  # a checkpoint the fp16 operand path cannot run: found
+                    prediction = self.model(x, cond_i)                    # now, not after the loop; repeated on the wide-range split
                 if drawn is not None:
                     torch.cuda.current_stream(x.device).wait_event(drawn)
                 x = self._posterior(x, prediction, noise, coef_i, mode_id)
@@ -456,7 +461,8 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
                         # q_step_from_x_0(known) and the mask blend are one kernel; the draw order (known-region noise,
                         # then p_step's noise) is the reference's
                         noise_k = self.randn_like(known, rng=rng)
-                        unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng)
+                        first = i == 0 and j == 0 and k == 0
+                        unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng, _early_check=num_steps * num_resample_steps * jump_length if first else 0)
                         x = _lib.repaint_blend(known, noise_k, unknown_s, mask, self._alpha_sigma_rows(r[:, k + 1]).to(dev))
                     x_s = x
                     if return_all:
@@ -542,6 +548,8 @@ class DiscreteTimeGaussianDiffusion(GaussianDiffusion):
             for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
                 noise, drawn = self._randn_like_ahead(x, rng=rng) if mode_id != _M_DT_DDIM else (None, None)
                 prediction = self.model(x, cond[i])
+                if i == 0 and _early_range_check(self.model, num_steps):
+                    prediction = self.model(x, cond[i])  # (repeated on the wide-range operand split)
                 if drawn is not None:
                     torch.cuda.current_stream(x.device).wait_event(drawn)
                 x = self._posterior(x, prediction, noise, coef[i], mode_id)

@@ -31,6 +31,11 @@ def count_parameters(model: torch.nn.Module) -> int:
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
 
 
+class UnsupportedArchitecture(TypeError, NotImplementedError):
+    """architecture='refinenet': a TypeError like the reference's own failure (and a NotImplementedError for callers of the
+    round-2 drop-in that caught that)."""
+
+
 def _denoiser(cfg: Config, max_batch: int) -> EfficientUNet:
     arch = cfg.model.architecture
     if arch == "refinenet":
@@ -39,8 +44,9 @@ def _denoiser(cfg: Config, max_batch: int) -> EfficientUNet:
         # (verified by running the reference's setup_model on a refinenet config).  No checkpoint of the LiDARGen
         # baseline can therefore reach the sampling path this package replaces; the drop-in keeps the reference's
         # error type and message and says why (branch closed, not built).
-        raise TypeError("'int' object is not iterable  [architecture='refinenet': the reference's setup_model raises this at "
-                        "utils/inference.py:54 (`sum(in_channels)` on an int); LiDARGenRefineNet is not part of the sampling path]")
+        raise UnsupportedArchitecture("architecture='refinenet' (LiDARGenRefineNet) is not part of the sampling path and is not built: the "
+                                      "reference's own setup_model cannot construct it either -- utils/inference.py:54 fails with "
+                                      "\"'int' object is not iterable\" (`sum(in_channels)` on an int)")
     if arch != "efficient_unet":
         raise ValueError(f"Unknown: {arch}")
     channels = int(bool(cfg.data.train_depth)) + int(bool(cfg.data.train_reflectance))
@@ -57,7 +63,7 @@ def _sampler(cfg: Config, model: EfficientUNet) -> GaussianDiffusion:
 
 
 def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, compile: bool = False,
-                max_batch: int = 8, precision: str = "fp32"):
+                max_batch: int = 8, precision: str = "fp32", strict_range: bool = False):
     """Build the sampler from a checkpoint (path or the dict ``train.py`` saves: cfg / weights / ema_weights /
     global_step, train.py:294-303).
 
@@ -66,6 +72,9 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
     (extension) is ``"fp32"`` (default: 22-bit split fp16 operands, parity mode), ``"fp32-bf16x3"`` (three bf16 pieces, parity mode with
     the full fp32 operand range) or ``"fp16"`` (one fp16 product per MAC: the reduced-precision bulk mode that mirrors the reference's
     fp16 autocast, sample_and_save.py:70; see ``EfficientUNet.set_precision``).
+    ``strict_range`` (extension): the default operand split passes operands through fp16 behind a data-driven range guard; when the
+    guard trips, the model switches itself to ``"fp32-bf16x3"`` with one ``RuntimeWarning`` and repeats the call (the reference runs
+    any finite checkpoint) -- ``strict_range=True`` raises ``R2DMRangeError`` instead.
     ``compile=True`` wraps the denoiser in ``torch.compile`` as upstream does; its forward is one ctypes call into the
     HIP library, i.e. a graph break that runs eagerly."""
     if isinstance(ckpt, (str, Path)):
@@ -76,6 +85,7 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
     ddpm.load_state_dict(ckpt["ema_weights" if ema else "weights"])
     ddpm.eval().requires_grad_(False).to(device)
     model.set_precision(precision)
+    model.strict_range = bool(strict_range)
     if compile:
         ddpm.model = torch.compile(ddpm.model)
 

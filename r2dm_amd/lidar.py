@@ -87,6 +87,4 @@ class LiDARUtility(nn.Module):
     def postprocess(self, sample):
         """(B,2,H,W) in [-1,1] -> (B,5,H,W) [depth, x, y, z, reflectance]
         (= `postprocess` of /root/reference/sample_and_save.py:52-57), one HIP launch."""
-        if self.depth_format != "log_depth":
-            raise NotImplementedError("fused post-processing is built for depth_format='log_depth' (the default)")
-        return _lib.lidar_postprocess(sample, self.ray_angles[0], self.min_depth, self.max_depth)
+        return _lib.lidar_postprocess(sample, self.ray_angles[0], self.min_depth, self.max_depth, self.depth_format)

@@ -174,6 +174,11 @@ class EfficientUNet(nn.Module):
         self._engine: Optional[_Engine] = None
         self._packed_for = None
         self.precision = "fp32"
+        # fp16 range guard of the default operand split: False (default) = a tripped guard switches this model to the wide-range split
+        # ("fp32-bf16x3": exact 24-bit operands, fp32 operand range, ~1.6x slower) with ONE warning and the forward is repeated --
+        # the reference samples any finite checkpoint (models/efficient_unet.py:269-295), so does the drop-in; True = raise R2DMRangeError
+        self.strict_range = False
+        self.range_fallbacks = 0  # how often that happened (0 or 1 per model: the switch is permanent)
         self._defer_range_check = False
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
@@ -289,12 +294,36 @@ class EfficientUNet(nn.Module):
         return self
 
     def check_range(self):
-        """Raise R2DMError if an f16x2 convolution since the last check may have seen operands outside the fp16 range
+        """Raise R2DMRangeError if an f16x2 convolution since the last check may have seen operands outside the fp16 range
         (synchronises the sampling stream).  Called after every stand-alone forward and at the end of a sampling loop."""
         if self._engine is not None and self._engine.blob is not None:
             dev = self._engine.blob.device
             with torch.cuda.device(dev):
-                _lib.check(_lib.lib().r2dm_check_range(self._engine.h, _lib.stream_ptr(dev)))
+                try:
+                    _lib.check(_lib.lib().r2dm_check_range(self._engine.h, _lib.stream_ptr(dev)))
+                except _lib.R2DMError as e:
+                    if "may be outside the fp16 range" in str(e):  # (not the packer's "weight is not finite" flag: no split can run that)
+                        raise _lib.R2DMRangeError(str(e)) from None
+                    raise
+
+    def check_range_or_fall_back(self) -> bool:
+        """``check_range``; if the guard tripped and ``strict_range`` is off, switch this model to ``"fp32-bf16x3"`` for good
+        (one warning) and return True: the caller repeats what it ran since the last check."""
+        try:
+            self.check_range()
+            return False
+        except _lib.R2DMRangeError as e:
+            if self.strict_range or self.precision == "fp32-bf16x3":
+                raise
+            import warnings
+
+            warnings.warn(f"r2dm_amd: the fp16 operand range guard tripped in precision={self.precision!r} ({e}); this checkpoint now runs on "
+                          "the wide-range operand split 'fp32-bf16x3' (same parity class, about 1.6x slower). "
+                          "Pass precision='fp32-bf16x3' to setup_model to start there, or strict_range=True to make this an error.",
+                          RuntimeWarning, stacklevel=3)
+            self.set_precision("fp32-bf16x3")
+            self.range_fallbacks += 1
+            return True
 
     @contextlib.contextmanager
     def deferred_range_check(self):
@@ -347,6 +376,7 @@ class EfficientUNet(nn.Module):
             raise ValueError(f"timesteps must have shape ({B},), got {tuple(timesteps.shape)}")
         self._ensure_packed(x.device)
         out = self._engine.forward(x, cond)
-        if not self._defer_range_check:
+        if not self._defer_range_check and self.check_range_or_fall_back():
+            out = self._engine.forward(x, cond)  # (again, on the wide-range split)
             self.check_range()
         return out

@@ -23,14 +23,17 @@ from r2dm_amd.distributed import broadcast_packed_weights, shard_seeds
 def sample(args):
     torch.set_grad_enabled(False)
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    local = local % max(torch.cuda.device_count(), 1)  # (tests: several ranks share one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as td
 
-        td.init_process_group("nccl", device_id=device)
+        # RCCL over xGMI ("nccl" IS RCCL on ROCm); R2DM_DIST_BACKEND=gloo lets two ranks share one GPU in tests (as bench.py)
+        backend = os.environ.get("R2DM_DIST_BACKEND", "nccl")
+        td.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
-    ddpm, lidar_utils, cfg = r2dm_amd.setup_model(args.ckpt, show_info=rank == 0, max_batch=args.batch_size,
+    ddpm, lidar_utils, cfg = r2dm_amd.setup_model(args.ckpt, show_info=rank == 0, max_batch=args.max_batch or args.batch_size,
                                                   precision=args.precision)
     ddpm.to(device)
     lidar_utils.to(device)
@@ -64,4 +67,5 @@ if __name__ == "__main__":
     parser.add_argument("--num_steps", type=int, default=256)
     parser.add_argument("--mode", choices=["ddpm", "ddim"], default="ddpm")
     parser.add_argument("--precision", choices=["fp32", "fp32-bf16x3", "fp16"], default="fp32")
+    parser.add_argument("--max-batch", type=int, default=0, help="extension: the batch size the layer tilings are planned for (default: --batch_size)")
     sample(parser.parse_args())

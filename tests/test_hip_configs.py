@@ -351,7 +351,7 @@ def test_f16x2_skip_convolution_input_range_fails_loudly():
     ck["ema_weights"] = dict(ck["ema_weights"])
     key = next(k for k in ck["ema_weights"] if k.endswith("u_block4.upsample.1.bias"))
     ck["ema_weights"][key] = torch.full_like(ck["ema_weights"][key], 1.0e5)
-    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2, strict_range=True)
     x, c = rnd(97, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
     with pytest.raises(R2DMError, match="fp16 range"):
         ddpm.model(x, c)
@@ -367,6 +367,7 @@ def test_f16x2_tracked_activation_range_fails_loudly():
     from r2dm_amd._lib import R2DMError
 
     ddpm = build(max_batch=2)
+    ddpm.model.strict_range = True  # (the default falls back to the wide-range split: tests/test_hip_range.py)
     x, c = rnd(96, 2, 2, 64, 1024).to(DEV), torch.zeros(2, device=DEV)
     assert torch.isfinite(ddpm.model(x, c)).all()  # ordinary inputs: no complaint
     with pytest.raises(R2DMError, match="fp16 range"):

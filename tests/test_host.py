@@ -106,6 +106,8 @@ def test_refinenet_config_fails_like_the_reference():
     ck["cfg"]["model"]["architecture"] = "refinenet"
     with pytest.raises(TypeError, match="'int' object is not iterable"):
         r2dm_amd.setup_model(ck, device="cpu", show_info=False)
+    with pytest.raises(NotImplementedError, match="refinenet"):  # (callers that caught round 2's error type keep working)
+        r2dm_amd.setup_model(ck, device="cpu", show_info=False)
     ck["cfg"]["model"]["architecture"] = "unet3"
     with pytest.raises(ValueError, match="Unknown: unet3"):
         r2dm_amd.setup_model(ck, device="cpu", show_info=False)

@@ -297,16 +297,25 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             for (int q = 0; q < Q; ++q) {
                 dma_stage(3 * q, ic<3>{});  // D0: stage 3q+3
                 dma_x((q + 1) & 1);         // x(q+1): its buffer was last read in chunk q-1
+                stamp(10);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N12) : "memory");  // stage 3q+1 landed
+                stamp(11);
                 __builtin_amdgcn_s_barrier();                               // #1
+                stamp(12);
                 asm volatile("" ::: "memory");
                 dma_stage(3 * q, ic<4>{});  // D1
+                stamp(13);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N12) : "memory");  // stage 3q+2 landed
+                stamp(14);
                 __builtin_amdgcn_s_barrier();                               // #2
+                stamp(15);
                 asm volatile("" ::: "memory");
                 dma_stage(3 * q, ic<5>{});  // D2
+                stamp(16);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");   // stage 3q+3 and x(q+1) landed
+                stamp(17);
                 __builtin_amdgcn_s_barrier();                               // #3: publishes x(q+1)
+                stamp(18);
                 asm volatile("" ::: "memory");
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing may outlive the block
@@ -1189,6 +1198,9 @@ static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
 template <int MRK>
 static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
     const long tiles = (long)(p.Cout / f2::Geo<MRK>::COT) * (p.W / f2::TW) * (p.H / f2::TH) * p.B;
+    if constexpr (MRK == 2) {  // pre-split input (presplit.hip): 64-channel tiles only
+        if (p.prologue == PRO_PRESPLIT) return p.pieces == 1 ? launch_f2<PRO_PRESPLIT, 1, 2>(p, tiles, s) : launch_f2<PRO_PRESPLIT, 2, 2>(p, tiles, s);
+    }
     if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
         switch (p.prologue) {
             case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK>(p, tiles, s);
@@ -1207,7 +1219,8 @@ static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
     if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile)) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
-    if (p.prologue != PRO_NONE && p.aff == nullptr) return hipErrorInvalidValue;
+    if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr) return hipErrorInvalidValue;
+    if (p.prologue == PRO_PRESPLIT && (p.co_tile != 64 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
 #ifndef F2_PROF
     if (p.prof != nullptr) return hipErrorInvalidValue;
 #endif

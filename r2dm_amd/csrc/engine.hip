@@ -476,6 +476,16 @@ struct Ctx {
         // allocation sequence, which must be the same in both walks)
         const bool fused_stats = sink && sink->p && emits_stats(L);
         if (sink && sink->p && !fused_stats) const_cast<Sink*>(sink)->incomplete = true;
+        // The operand pre-pass (presplit.hip) is an EXPERIMENT, off by default: R2DM_F2_PRESPLIT_MIN_COUT=256 sends the layers with >= 256
+        // output channels through it.  Round-4 A/B (profiles/r04_presplit.txt): bit-identical outputs, conv_f16x2's own roofline fraction
+        // 0.387 -> 0.403, the STEP 1.7 % slower (6.19 -> 6.30 ms): the pass costs more than the staging waves' transform did -- with the
+        // stagers idle a chunk still takes 4.5 k cycles (multipliers + three barriers), and the board answers the denser MFMA stream with a
+        // lower clock.  (decided in both walks: the allocation sequence must be the same)
+        static const int presplit_min_cout = getenv("R2DM_F2_PRESPLIT_MIN_COUT") ? atoi(getenv("R2DM_F2_PRESPLIT_MIN_COUT")) : 0;  // (0: never)
+        const bool f2_launch = L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded);
+        float* xs = nullptr;
+        if (f2_launch && L.f2_cot == 64 && presplit_min_cout > 0 && L.cout >= presplit_min_cout && presplit_supported(x, L.cin, H, W))
+            xs = (float*)ar->alloc((size_t)presplit_floats(B, L.cin, H, W) * sizeof(float));
         if (!dry()) {
             ConvParams p;
             p.x = x;
@@ -508,6 +518,13 @@ struct Ctx {
                 p.wscale = blob(L.ws_f2) + 1;
                 p.co_tile = L.f2_cot;
                 p.pieces = h->conv_pieces;
+            }
+            // deep layers (many 64-channel output tiles): the input transform once, by the pre-pass (presplit.hip)
+            if (xs) {
+                note(launch_presplit(x, aff, pro, xs, B, L.cin, H, W, st), "presplit");
+                p.x = Src{xs, nullptr, L.cin, 0, presplit_floats(1, L.cin, H, W), 0};
+                p.prologue = PRO_PRESPLIT;
+                p.aff = nullptr;
             }
             if (L.p1 && h->f16_path() && pro != PRO_AFFINE_SILU && (pro != PRO_NONE || input_bounded)) {
                 p.algo = ALGO_P1F16;
@@ -554,6 +571,7 @@ struct Ctx {
             note(launch_conv(p, st), "conv");
             if (e1) (void)hipEventRecord(e1, st);
         }
+        if (xs) ar->release(xs);  // (stream-ordered: the next user of that memory is enqueued behind this convolution)
         return y;
     }
 
@@ -1063,6 +1081,24 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.prologue = prologue;
     // perf probe (scripts/conv_phases.py): per-block s_memtime stamps into a caller-provided device buffer
     if (const char* e = getenv("R2DM_CONV_PROF_PTR")) p.prof = (unsigned long long*)strtoull(e, nullptr, 0);
+    // per-kernel tests / probes of the operand pre-pass (presplit.hip + conv_f16x2's PRO_PRESPLIT stagers): R2DM_F2_PRESPLIT=1
+    float* xs = nullptr;
+    if (const char* e = getenv("R2DM_F2_PRESPLIT"); e && atoi(e) && p.algo == ALGO_F16X2 && p.co_tile == 64 && presplit_supported(p.x, cin, H, W)) {
+        static float* scratch = nullptr;  // (test entry: one growing scratch buffer, never freed)
+        static size_t scratch_floats = 0;
+        const size_t need = (size_t)presplit_floats(B, cin, H, W);
+        if (need > scratch_floats) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (scratch) HIP_TRY(hipFree(scratch));
+            HIP_TRY(hipMalloc(&scratch, need * sizeof(float)));
+            scratch_floats = need;
+        }
+        xs = scratch;
+        HIP_TRY(launch_presplit(p.x, p.aff, prologue, xs, B, cin, H, W, st));
+        p.x = Src{xs, nullptr, cin, 0, presplit_floats(1, cin, H, W), 0};
+        p.prologue = PRO_PRESPLIT;
+        p.aff = nullptr;
+    }
     HIP_TRY(launch_conv(p, st));
     return 0;
 }

@@ -7,8 +7,8 @@ cd "$(dirname "$0")/../r2dm_amd/csrc"
 out=../../build_probe/obj_$name
 mkdir -p $out
 pids=()
-for f in conv_mfma conv_bf16x3 conv_f16x2 proj_f16x2 conv_direct norm resample attention embed posterior engine; do
-  extra=""; case $f in conv_bf16x3*|conv_f16x2|proj_f16x2) extra="-fno-slp-vectorize";; esac
+for f in conv_mfma conv_bf16x3 conv_f16x2 proj_f16x2 presplit conv_direct norm resample attention embed posterior engine; do
+  extra=""; case $f in conv_bf16x3*|conv_f16x2|proj_f16x2|presplit) extra="-fno-slp-vectorize";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f.hip -o $out/$f.o 2> $out/$f.err &
   pids+=($!)
 done

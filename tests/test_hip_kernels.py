@@ -129,6 +129,35 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
         assert not torch.equal(out["f16x2/64"], out["f16x2/128"])  # (the 128-channel tile really ran)
 
 
+@pytest.mark.parametrize("pro", [0, 1, 2])
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 256), (256, 256, 8, 128), (512, 256, 4, 64)])
+def test_conv3x3_operand_prepass_is_bit_identical(H, cin, cout, h, w, pro):
+    """The operand pre-pass experiment (presplit.hip): GroupNorm-affine + SiLU + f16 split applied once, the
+    convolution's staging waves only issue LDS-DMA (conv_f16x2 PRO_PRESPLIT).  Same arithmetic in the same order: the output must
+    equal the default path's bit for bit -- every prologue, both precision modes that use the kernel, image rows at the top and
+    bottom of a tile (zero rows of the layout) and the azimuth wrap (lane addresses)."""
+    B = 3
+    x, wt, b = rnd(11, B, cin, h, w).to(DEV), (rnd(12, cout, cin, 3, 3) / math.sqrt(9 * cin)).to(DEV), rnd(13, cout).to(DEV)
+    res = rnd(14, B, cout, h, w).to(DEV)
+    aff = torch.stack([torch.rand(B, cin) + 0.5, torch.randn(B, cin) * 0.3], -1).contiguous().to(DEV) if pro else None
+    saved = {k: os.environ.get(k) for k in ("R2DM_F2_PRESPLIT", "R2DM_F2_CO_TILE")}
+    try:
+        os.environ["R2DM_F2_CO_TILE"] = "64"
+        for pieces in (2, 1):
+            H.set_conv_pieces(pieces)
+            out = {}
+            for pre in ("0", "1"):
+                os.environ["R2DM_F2_PRESPLIT"] = pre
+                out[pre] = H.conv2d_ring(x, wt, b, aff=aff, prologue=pro, residual=res, scale=0.70710678)
+            assert torch.isfinite(out["1"]).all() and torch.equal(out["0"], out["1"]), (pieces, (out["0"] - out["1"]).abs().max().item())
+    finally:
+        H.set_conv_pieces(2)
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
 def test_conv3x3_batch_tiling_variants(O, H):
     # large batch*pixels switches Cout%128==0 layers to the 128-channel tile (conv_pick_co_tile)
     x, wt, b = rnd(4, 8, 32, 64, 256), rnd(5, 128, 32, 3, 3) / math.sqrt(288), rnd(6, 128)

@@ -318,9 +318,14 @@ def test_operand_split_modes_are_both_parity_modes():
     net.set_precision("fp32")
     assert torch.equal(net(x.to(DEV), c.to(DEV)).cpu(), ya) and not torch.equal(ya, yb)
     ra, rb = rms(ya, truth), rms(yb, truth)
-    print(f"U-Net 64x1024 vs fp64: f16x2 mode rms {ra:.2e} max {max_abs(ya, truth):.2e} | bf16x3 mode rms {rb:.2e} max {max_abs(yb, truth):.2e}")
+    # the yardstick (bars relative to an fp32 evaluation measured in the same test, not to each other): the
+    # reference's own arithmetic on this GPU -- the oracle in fp32 on stock PyTorch-ROCm (MIOpen / rocBLAS)
+    yr = O.unet_forward({k: v.to(DEV) for k, v in sd.items()}, O.UNetConfig(), x.to(DEV), c.to(DEV)).cpu()
+    rr = rms(yr, truth)
+    print(f"U-Net 64x1024 vs fp64: f16x2 mode rms {ra:.2e} max {max_abs(ya, truth):.2e} | bf16x3 mode rms {rb:.2e} max {max_abs(yb, truth):.2e} | "
+          f"the reference's fp32 on PyTorch-ROCm rms {rr:.2e} max {max_abs(yr, truth):.2e}")
     assert ra < 4e-7 and rb < 5.5e-7 and max_abs(ya, truth) < 8e-6 and max_abs(yb, truth) < 8e-6  # ~2x measured
-    assert ra < 1.1 * rb
+    assert ra <= rr and rb <= rr  # both parity modes are at least as close to exact arithmetic as the reference's fp32 GPU evaluation
     with pytest.warns(DeprecationWarning):
         net.set_precision("bf16x2")  # round 1's reduced mode: kept as a deprecated alias of the (faster, more accurate) default
     assert net.precision == "fp32" and torch.equal(net(x.to(DEV), c.to(DEV)).cpu(), ya)

@@ -267,3 +267,41 @@ def test_coordinate_encodings_match_reference(golden):
         assert c.shape == g[f"cenc_{enc}"].shape and (c - g[f"cenc_{enc}"]).abs().max() < 3e-7, enc
     with pytest.raises(ValueError):
         E.coord_channels("cubemap", GOLDEN_RES)
+
+
+def test_range_guard_fallback_host_logic():
+    """The host side of the fp16 range guard's fallback (r2dm_amd/diffusion.py::_early_range_check, EfficientUNet.strict_range): with
+    strict_range the early check only runs for loops longer than 8 steps and raises; otherwise it runs for every step count and
+    reports a fallback, through a torch.compile wrapper (`_orig_mod`) too.  (The kernels' side: tests/test_hip_range.py, -m gpu.)"""
+    import r2dm_amd
+    from r2dm_amd import diffusion
+    from r2dm_amd._lib import R2DMError, R2DMRangeError
+
+    class Fake:
+        def __init__(self, strict, trips):
+            self.strict_range, self.trips, self.calls = strict, trips, 0
+
+        def check_range_or_fall_back(self):
+            self.calls += 1
+            if self.trips and self.strict_range:
+                raise R2DMRangeError("an input of the fp16-operand convolution path may be outside the fp16 range")
+            return self.trips
+
+    class Wrapper:  # what torch.compile returns
+        def __init__(self, m):
+            self._orig_mod = m
+
+    assert issubclass(R2DMRangeError, R2DMError)
+    m = Fake(strict=False, trips=True)
+    assert diffusion._early_range_check(m, 2) is True and diffusion._early_range_check(Wrapper(m), 256) is True and m.calls == 2
+    m = Fake(strict=False, trips=False)
+    assert diffusion._early_range_check(m, 2) is False and m.calls == 1
+    m = Fake(strict=True, trips=True)
+    assert diffusion._early_range_check(m, 8) is False and m.calls == 0  # short loops: the deferred check at the loop's end reports it
+    with pytest.raises(R2DMRangeError):
+        diffusion._early_range_check(m, 9)
+    assert diffusion._early_range_check(object(), 100) is False  # any other denoiser: nothing to check
+    ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(resolution=GOLDEN_RES), device="cpu", show_info=False, strict_range=True)
+    assert ddpm.model.strict_range is True and ddpm.model.range_fallbacks == 0
+    ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(resolution=GOLDEN_RES), device="cpu", show_info=False)
+    assert ddpm.model.strict_range is False

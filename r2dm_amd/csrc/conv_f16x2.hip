@@ -35,6 +35,12 @@
 // Three block-wide barriers per chunk (one per weight stage) couple the two groups.  The block is persistent (one per
 // CU) and walks its share of the launch's (output channel tile, pixel tile) pairs; the stagers run ahead across tile
 // boundaries, so a tile's epilogue overlaps the staging of the next tile's first chunks.
+//
+// Round 4: a third template parameter.  MRK = 2 is the kernel described above (64-channel output tiles, two accumulators);
+// MRK = 4 gives a multiplying wave four 32-channel row blocks -- 128-channel output tiles, 24 MFMAs and 12 fragment reads per tap,
+// half the staging work per MFMA -- with ONE accumulator for all three products (residual planes at their true scale, a weight
+// packing of its own): fp32-class up to Cin = 128, which is where conv_f16x2_pick_co_tile uses it.
+// PRO_PRESPLIT: the input arrives pre-split (presplit.hip) and the stagers only issue LDS-DMA -- an experiment, off by default.
 #include "common.h"
 #include "conv_bf16x3.h"
 #include "conv_epilogue.h"

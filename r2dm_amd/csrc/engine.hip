@@ -479,8 +479,8 @@ struct Ctx {
         // The operand pre-pass (presplit.hip) is an EXPERIMENT, off by default: R2DM_F2_PRESPLIT_MIN_COUT=256 sends the layers with >= 256
         // output channels through it.  Round-4 A/B (profiles/r04_presplit.txt): bit-identical outputs, conv_f16x2's own roofline fraction
         // 0.387 -> 0.403, the STEP 1.7 % slower (6.19 -> 6.30 ms): the pass costs more than the staging waves' transform did -- with the
-        // stagers idle a chunk still takes 4.5 k cycles (multipliers + three barriers), and the board answers the denser MFMA stream with a
-        // lower clock.  (decided in both walks: the allocation sequence must be the same)
+        // stagers idle a chunk still takes 4.5 k cycles (multipliers + three barriers; 5.2 k before), prologue / tile ends / tail are unchanged.
+        // (decided in both walks: the allocation sequence must be the same)
         static const int presplit_min_cout = getenv("R2DM_F2_PRESPLIT_MIN_COUT") ? atoi(getenv("R2DM_F2_PRESPLIT_MIN_COUT")) : 0;  // (0: never)
         const bool f2_launch = L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded);
         float* xs = nullptr;

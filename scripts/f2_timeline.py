@@ -10,6 +10,7 @@ os.environ["R2DM_CONV_PROF_PTR"] = str(prof.data_ptr())
 from r2dm_amd import _lib
 from bench_conv_shapes import SHAPES
 L = _lib.lib(); st = torch.cuda.current_stream().cuda_stream
+_lib.check(L.r2dm_set_conv_pieces(None, int(os.environ.get('PIECES', '2'))))  # 1: the fp16 bulk mode's kernels
 NAMES = {1: "M arr#1", 2: "M arr#2", 3: "M arr#3", 4: "M lv#1", 5: "M lv#2", 6: "M lv#3", 7: "M epi begin", 8: "M epi end", 20: "M epi bias+res requested", 26: "M epi accumulators merged", 27: "M epi residual requested", 28: "M epi q0 turned", 21: "M epi quarter 0 done", 22: "M epi m=0 quarters done", 23: "M epi m=0 stats written", 24: "M epi m=1 quarters done", 25: "M epi m=1 stats written",
          30: "h start", 50: "h cursors set", 51: "h ad4 requested", 52: "h ring requested", 53: "h table requested", 54: "h chunk 0 requested", 31: "h prologue loads issued", 32: "h chunk 0 landed", 33: "h chunk 0 transformed", 34: "h arr P", 35: "h lv P", 36: "M arr P", 37: "M lv P", 60: "M slice begin", 61: "M slice operands landed", 62: "M slice quarter stored", 63: "M slice end", 40: "M tail begin", 41: "M tail q1", 42: "M tail q2", 43: "M tail q3",
          10: "h xf0 done", 11: "h arr#1", 12: "h lv#1", 13: "h xf1 done", 14: "h arr#2", 15: "h lv#2", 16: "h loads issued", 17: "h arr#3", 18: "h lv#3"}

@@ -322,7 +322,7 @@ def main():
                                      ("fp16 operands (the fp16 piece of the split alone), 1 product per MAC, fp32 accumulation" if args.precision == "fp16" else
                                       "fp32 operands split to 22 bits (fp16 + 2^11-scaled fp16 residual), 3 products per fp32 product (the "
                                       "residual x residual term, 2^-22 relative, is dropped), two fp32 accumulators per 64-channel output tile, one per "
-                                      "128-channel tile (the Cin <= 128 layers with >= 256 such tiles)") +
+                                      "128-channel tile (the Cin <= 256 layers with >= 256 such tiles)") +
                                      "; fused GN+SiLU prologue, residual / GroupNorm-statistics epilogue; warp-specialised, persistent",
                 "conv_bf16x3_*": "same contract on the bf16 matrix pipe: three bf16 pieces, 6 products per fp32 product",
                 "1x1 / in / out convolutions": "proj_f16x2_kernel (1x1 skips and attention projections: split fp16 operands; fp32-input MFMA with precision fp32-bf16x3), conv_few_in_kernel (in_conv), conv_direct_rows_kernel (out_conv)"}

@@ -39,7 +39,7 @@
 // Round 4: a third template parameter.  MRK = 2 is the kernel described above (64-channel output tiles, two accumulators);
 // MRK = 4 gives a multiplying wave four 32-channel row blocks -- 128-channel output tiles, 24 MFMAs and 12 fragment reads per tap,
 // half the staging work per MFMA -- with ONE accumulator for all three products (residual planes at their true scale, a weight
-// packing of its own): fp32-class up to Cin = 128, which is where conv_f16x2_pick_co_tile uses it.
+// packing of its own): below an fp32 fmaf chain's rms error at every depth; conv_f16x2_pick_co_tile uses it up to Cin = 256.
 // PRO_PRESPLIT: the input arrives pre-split (presplit.hip) and the stagers only issue LDS-DMA -- an experiment, off by default.
 #include "common.h"
 #include "conv_bf16x3.h"
@@ -1140,10 +1140,12 @@ long conv_f16x2_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 *
 int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch) {
     const bool wide_ok = conv_f16x2_supported(Cin, Cout, 9, H, W, 128);
     if (const char* e = getenv("R2DM_F2_CO_TILE")) return atoi(e) == 128 && wide_ok ? 128 : 64;  // (read per call: per-kernel tests switch it)
-    // The one-accumulator tile takes three truncating accumulator updates per tap where the 64-channel tile takes one: its rms error
-    // stays below the fp32-MFMA kernel's (an exact fmaf chain, two-level above 128 channels) up to Cin = 128 (K = 1152) -- measured in
-    // tests/test_hip_kernels.py::test_conv3x3_both_operand_splits -- and is 1.2x / 1.7x of it at Cin = 256 / 512: not used there
-    return wide_ok && Cin <= 128 && (pixels_times_batch / (f2::TH * f2::TW)) * (Cout / 128) >= f2_cu_count() ? 128 : 64;
+    // The one-accumulator tile takes three truncating accumulator updates per tap where the 64-channel tile takes one.  Measured per layer
+    // against fp64 (tests/test_hip_kernels.py::test_conv3x3_both_operand_splits): its rms error is 0.4-0.6x a plain fp32 fmaf chain's (the
+    // fp32-MFMA kernel with one accumulator) at every depth, 0.66-0.70x the library's fp32 kernel at Cin <= 128, 1.2x at Cin = 256 and 1.7x at
+    // Cin = 512, where that kernel accumulates on two levels.  Used up to Cin = 256 (R2DM_F2_WIDE_MAX_CIN: experiments).
+    static const int max_cin = getenv("R2DM_F2_WIDE_MAX_CIN") ? atoi(getenv("R2DM_F2_WIDE_MAX_CIN")) : 256;
+    return wide_ok && Cin <= max_cin && (pixels_times_batch / (f2::TH * f2::TW)) * (Cout / 128) >= f2_cu_count() ? 128 : 64;
 }
 
 // max_bits <- float bits of max|w[0 .. n)| (non-negative floats order like their bit patterns; NaN sorts above infinity)

@@ -614,8 +614,9 @@ hipError_t launch_conv(const ConvParams& p, hipStream_t s) {
 #ifdef R2DM_ACC2_ALL
             if (true) return launch_pro<9, 64, 1, 4, kCK3_64_DEEP, true, 2>(p, s);
 #endif
-            return p.Cin > 128 ? launch_pro<9, 64, 1, 4, kCK3_64_DEEP, true, 2>(p, s)
-                               : launch_pro<9, 64, 1, 4, kCK3_64, false, 3>(p, s);
+            // (pieces == 5: per-kernel test hook -- ONE accumulator at any depth, i.e. the plain fmaf chain the split kernels are measured against)
+            return p.Cin > 128 && p.pieces != 5 ? launch_pro<9, 64, 1, 4, kCK3_64_DEEP, true, 2>(p, s)
+                                                : launch_pro<9, 64, 1, 4, kCK3_64, false, 3>(p, s);
         }
         if (p.co_tile == 32) return launch_pro<9, 32, 1, 4, kCK3_32, false, 3>(p, s);
     } else if (p.taps == 1) {

@@ -958,8 +958,8 @@ int r2dm_lidar_postprocess_fmt(const float* x, const float* ang, float* out, int
 static int g_single_kernel_pieces = 2;  // r2dm_conv2d_ring (per-op tests)
 
 int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces) {
-    if (!h && pieces == 4) {  // per-op tests only: the fp32-input MFMA (an exact fmaf chain) as the yardstick of the split-operand kernels
-        g_single_kernel_pieces = 4;
+    if (!h && (pieces == 4 || pieces == 5)) {  // per-op tests only: the fp32-input MFMA kernel as the yardstick of the split-operand kernels --
+        g_single_kernel_pieces = pieces;       // 4: as the library runs it (two-level accumulation above 128 channels), 5: a plain fmaf chain
         return 0;
     }
     if (pieces < 1 || pieces > 3)
@@ -1042,7 +1042,10 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.taps = ksize * ksize;
     p.pieces = 3;
     p.algo = conv_pick_algo(cin, cout, p.taps);
-    if (g_single_kernel_pieces == 4 && p.algo != ALGO_DIRECT) p.algo = ALGO_F32;  // (test hook: the fp32-input MFMA kernel)
+    if (g_single_kernel_pieces >= 4 && p.algo != ALGO_DIRECT) {  // (test hook: the fp32-input MFMA kernel)
+        p.algo = ALGO_F32;
+        p.pieces = g_single_kernel_pieces;
+    }
     if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale || W % 4 != 0)) p.algo = ALGO_F32;  // plain convolutions of 16-byte rows only
                                                                                                              // (any other width runs on the fp32-MFMA kernel)
     // per-op tests: with pieces = 2 every shape the f16x2 kernel covers goes there (the engine restricts it to normalised inputs)

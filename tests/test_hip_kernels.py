@@ -84,11 +84,11 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
     with two accumulators and (round 4) 128-channel tiles with one (conv_f16x2.hip, pieces = 2); three bf16 pieces, six products
     (conv_bf16x3.hip, pieces = 3) -- against an fp64 convolution, every prologue, with residual and scale, next to the
     fp32-input MFMA kernel (conv_mfma.hip: an exact fmaf chain, pieces = 4 of the test hook) measured in the same test.  All are
-    fp32-class: max error < 1e-5 on O(1) outputs.  The bar of the split kernels is the library's own fp32 kernel (an fmaf chain up to
-    Cin = 128, two-level accumulation above): rms error <= its rms error up to Cin = 128, <= 1.1x above (both two-level class).
-    Measured (round 4, gpurun_out/j207): the two-accumulator tile at 0.4-0.5x of it up to Cin = 128 and 0.75-1.0x above; the
-    one-accumulator tile (three truncating accumulator updates per tap instead of one) at 0.66-0.7x up to Cin = 128 and 1.2x / 1.7x
-    at Cin = 256 / 512 -- which is why conv_f16x2_pick_co_tile selects it for Cin <= 128 only (asserted here as < 2x, experimental)."""
+    fp32-class: max error < 1e-5 on O(1) outputs.  Two yardsticks measured in the same test: the fp32-MFMA kernel as ONE fmaf chain
+    (pieces = 5: what fp32 arithmetic is) and as the library runs it (pieces = 4: two-level accumulation above 128 channels).  Bars:
+    every split kernel's rms error <= the plain chain's, at every depth; the two-accumulator tile <= 1.1x the two-level kernel's; the
+    one-accumulator tile (three truncating accumulator updates per tap instead of one) <= 1.0x of it up to Cin = 128 and <= 1.3x at
+    Cin = 256 -- the depths conv_f16x2_pick_co_tile uses it at (measured 0.66-0.70x / 1.2x; 1.7x at Cin = 512: not dispatched there)."""
     import torch.nn.functional as F
 
     B = 3
@@ -102,7 +102,7 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
         xa = F.silu(xa)
     ref = (res.double() + O.conv_ring(xa, wt.double(), b.double())) * 0.70710678
     out = {}
-    variants = [("f16x2/64", 2, "64"), ("bf16x3", 3, None), ("f32 mfma", 4, None)] + ([("f16x2/128", 2, "128")] if cout % 128 == 0 else [])
+    variants = [("f16x2/64", 2, "64"), ("bf16x3", 3, None), ("f32 mfma", 4, None), ("f32 chain", 5, None)] + ([("f16x2/128", 2, "128")] if cout % 128 == 0 else [])
     saved = os.environ.get("R2DM_F2_CO_TILE")
     for name, pieces, tile in variants:
         H.set_conv_pieces(pieces)
@@ -119,12 +119,15 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
     e = {k: (max_abs(v, ref), (v.double() - ref).pow(2).mean().sqrt().item()) for k, v in out.items()}
     print(f"conv {cin}->{cout} pro={pro}: " + " | ".join(f"{k} max {v[0]:.2e} rms {v[1]:.2e}" for k, v in e.items()))
     assert not torch.equal(out["f16x2/64"], out["bf16x3"]) and not torch.equal(out["f16x2/64"], out["f32 mfma"])  # the mode switches took effect
-    assert all(v[0] < 1e-5 for v in e.values())
+    assert all(v[0] < 1e-5 for k, v in e.items() if k != "f32 chain")  # (the plain chain is a yardstick, not a product path: 1.0e-5 at K = 4608)
     assert e["f16x2/64"][1] < (0.75 if cin <= 128 else 1.5) * e["bf16x3"][1]
     for k in ("f16x2/64", "f16x2/128"):
         if k in e:
-            bar = 1.0 if cin <= 128 else (1.1 if k == "f16x2/64" else 2.0)
+            assert e[k][1] <= e["f32 chain"][1], (k, e)  # at or below an fp32 fmaf chain, at every depth
+            bar = 1.0 if cin <= 128 else 1.1 if k == "f16x2/64" else 1.3 if cin <= 256 else 2.0
             assert e[k][1] <= bar * e["f32 mfma"][1], (k, e)
+    if cin > 128:
+        assert not torch.equal(out["f32 mfma"], out["f32 chain"]) and e["f32 mfma"][1] < e["f32 chain"][1]  # (the hook took effect; two levels pay)
     if "f16x2/128" in e:
         assert not torch.equal(out["f16x2/64"], out["f16x2/128"])  # (the 128-channel tile really ran)
 

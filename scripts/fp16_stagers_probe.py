@@ -25,7 +25,7 @@ SHAPES = {  # name: (cin, cout, h, w, prologue, residual)
 dev = "cuda"
 L = _lib.lib()
 _lib.check(L.r2dm_set_conv_pieces(None, int(os.environ.get("PIECES", "1"))))
-os.environ["R2DM_F2_CO_TILE"] = "64"
+os.environ["R2DM_F2_CO_TILE"] = os.environ.get("COT", "64")
 st = torch.cuda.current_stream().cuda_stream
 iters = int(os.environ.get("ITERS", "20"))
 for n, (cin, cout, h, w, pro, res) in SHAPES.items():

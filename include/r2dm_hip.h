@@ -99,6 +99,10 @@ int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
  * calls this after every stand-alone forward and once at the end of a sampling loop. */
 int r2dm_check_range(r2dm_handle* h, void* stream);
 
+/* Test hook: raises the recorded operand bound to at least `bound` on `stream`, as a convolution input of that size would have
+ * (tests/test_hip_range.py simulates a guard trip at a chosen step of a sampling loop with it). */
+int r2dm_test_raise_range_bound(r2dm_handle* h, float bound, void* stream);
+
 /* -- measurement aid (bench.py): when enabled, every convolution launch of a forward -- conv_f16x2_kernel (54 3x3 launches in
  *    the default mode; conv_bf16x3_* with pieces = 3), proj_f16x2_kernel (8 1x1 launches; conv_mfma_kernel with pieces = 3) and
  *    the two direct kernels (in_conv, out_conv), 64 launches per forward -- is bracketed by hipEvents recorded on the caller's stream.  r2dm_profile_read waits for them and returns the summed kernel time, the summed

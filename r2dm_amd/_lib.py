@@ -24,6 +24,12 @@ class R2DMRangeError(R2DMError):
     """The fp16-operand paths' range guard tripped (r2dm_check_range): results of the forwards since the last check are not valid."""
 
 
+class R2DMRangeFallback(R2DMRangeError):
+    """The guard tripped at the end of a loop that cannot replay itself (a hand-written ``p_step`` loop under
+    ``deferred_range_check``): the denoiser has switched to the wide-range operand split, the loop's results are not valid, and
+    repeating the call gives them (``repaint`` does that itself, from the saved generator states)."""
+
+
 class Config(Structure):
     _fields_ = [
         ("in_channels", c_int32),
@@ -62,6 +68,7 @@ SIGNATURES = {
     "r2dm_unet_forward": (c_int32, [_P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "r2dm_set_conv_pieces": (c_int32, [_P, c_int32]),
     "r2dm_check_range": (c_int32, [_P, _P]),
+    "r2dm_test_raise_range_bound": (c_int32, [_P, c_float, _P]),
     "r2dm_profile_enable": (c_int32, [_P, c_int32]),
     "r2dm_profile_read": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "r2dm_profile_read_classes": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),

@@ -72,6 +72,7 @@ struct ConvParams {
     int B, H, W, Cin, CinPad, Cout;
     int taps;            // 9 or 1
     int co_tile;         // 32 / 64 / 128 (must match the packing)
+    int px_rows = 4;     // ALGO_F16X2: image rows per pixel tile -- 4, or 8 with co_tile 64 (conv_f16x2.hip's one-accumulator "tall" tile; must match the packing)
     int prologue;        // Prologue
     int algo = ALGO_F32; // ConvAlgo (must match the packing of `w`)
     int pieces = 3;      // ALGO_BF16X3: bf16 pieces per fp32 operand (3 = exact split, 6 products; the 2-piece variant of
@@ -111,15 +112,17 @@ long conv_bf16x3_packed_floats(int Cin, int Cout);
 int conv_bf16x3_co_tile(int Cin, int Cout, long pixels_times_batch);
 hipError_t launch_pack_conv_bf16x3(const float* w_oihw, float* dst, int Cout, int Cin, int co_tile, hipStream_t s);
 hipError_t launch_conv_bf16x3(const ConvParams& p, hipStream_t s);
-bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile = 64);  // co_tile: 64 | 128 (conv_f16x2.hip)
+bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile = 64, int px_rows = 4);  // tiles 64 x 4 | 128 x 4 | 64 x 8 (conv_f16x2.hip)
 long conv_f16x2_packed_floats(int Cin, int Cout);
-// 128-channel output tiles (one accumulator) where the launch still has a tile per CU at the planned batch, else 64 (two accumulators);
-// env R2DM_F2_CO_TILE = 64 | 128 forces one of them where the shape allows (experiments, per-kernel tests)
-int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch);
+// One-accumulator tiles where the launch still has a tile per CU at the planned batch -- 128 channels x 4 rows, or 64 x 8 for layers with
+// fewer than 128 output channels --, else 64 x 4 (two accumulators).  Returns the channels, *px_rows the rows (nullptr: 4-row tiles only);
+// env R2DM_F2_CO_TILE = 64 | 128 | 64x8 forces one of them where the shape allows (experiments, per-kernel tests)
+int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch, int* px_rows = nullptr);
 // range_flag (device int, may be nullptr): bit 0 is set if a weight does not fit the fp16 range
 // wscale (device float[2], may be nullptr = unscaled): [0] scratch (max|w| as float bits), [1] <- the inverse of the power-of-two
 // scale applied to the layer's weights (ConvParams::wscale points there)
-hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr, int co_tile = 64);
+hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr, int co_tile = 64,
+                                  int px_rows = 4);
 hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream_t s);  // max_bits <- float bits of max|w| (zeroed first)
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s);
 // the operand pre-pass of conv_f16x2 (presplit.hip): xs <- [b][chunk][plane][group][H + 2][W][8 ch] fp16 of silu(x a + d) (prologue as in

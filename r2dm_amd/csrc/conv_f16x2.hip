@@ -46,30 +46,43 @@
 #include "conv_epilogue.h"
 #include "f16x2.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace r2dm {
 
 namespace f2 {
-using namespace x3;  // CO_T 64, TH 4, TW 64, XR 6, NG 2, CK 16, MR 2, NR 2
+using namespace x3;  // CO_T 64, TW 64, NG 2, CK 16 (TH / XR / MR / NR of x3 are the (2, 2) tile's: the kernel shadows them per tile)
 constexpr int NPL = 2;                                      // planes: h, l
 constexpr int XS = 67;                                      // 66 columns + 1 dump column (never read)
-constexpr int XPL = NG * XR * XS;                           // 16-byte entries per plane
-constexpr int XBYTES = NPL * XPL * 16;                      // 25728
 constexpr int ADTAB_BYTES = 4096;                           // (a, d) of the current tile's sample, all Cin channels: Cin <= 512
-// MRK = 32-channel row blocks per multiplying wave: 2 = 64-channel output tiles, two accumulators per MFMA tile (round 2);
-// 4 = 128-channel output tiles, ONE accumulator (round 4: half the staging work and x-fragment reads per MFMA)
-template <int MRK>
+// A multiplying wave owns MRK 32-channel row blocks x NRK 32-pixel segments (two segments per image row, four waves):
+//   (MRK, NRK) = (2, 2): 64 channels x 4 rows x 64 pixels, two accumulators per MFMA tile (round 2)
+//                (4, 2): 128 channels x 4 rows, ONE accumulator (round 4: half the staging work and x-fragment reads per MFMA)
+//                (2, 4): 64 channels x 8 rows, ONE accumulator (round 5, the "tall" tile: what the 128-channel tile is to layers with
+//                        >= 128 output channels, for the layers with 64: 24 MFMAs per tap between two barriers, a halo of 10 / 8 instead
+//                        of 6 / 4 rows, one tile end per 512 pixels)
+//                (2, 1): 64 channels x 2 rows, two accumulators (round 5, the "short" tile: twice the tiles where a launch has fewer
+//                        tiles than the chip has CUs)
+template <int MRK, int NRK>
 struct Geo {
     static constexpr int COT = 32 * MRK;                        // output channels per tile
+    static constexpr int TH = 2 * NRK;                          // image rows per tile
+    static constexpr int XR = TH + 2;                           // ... and of its input tile
+    static constexpr int XPL = NG * XR * XS;                    // 16-byte entries per plane
+    static constexpr int XBYTES = NPL * XPL * 16;               // 25728 (four rows) | 42880 (eight) | 17152 (two)
+    static constexpr int NQ = MRK * NRK;                        // 32 x 32 quarters of a multiplying wave's tile
+    static constexpr bool ONEACC = NQ == 8;                     // all three products into one accumulator (l planes at their true scale)
     static constexpr int WSTAGE = NPL * 3 * NG * COT * 16;      // 12288 / 24576: one kernel row of one chunk
-    static constexpr int RING = MRK == 2 ? 4 : 3;               // weight stages in LDS
+    static constexpr int RING = ONEACC ? 3 : 4;                 // weight stages in LDS
     static constexpr int WB0 = 2 * XBYTES;                      // [x buffer 0][x buffer 1][weight ring][epilogue patches][finished tile][(a, d) table]
-    static constexpr int PATCH0 = WB0 + RING * WSTAGE;          // 100608 / 125184
-    static constexpr int RESQ = MRK == 2 ? 3 : 2;               // quarters of a finished tile that wait in LDS for their deferred epilogue (per wave; of 4 / of 8)
-    static constexpr int RES0 = PATCH0 + (MRK == 2 ? 4 * 1024 : 0);  // four waves x RESQ x 4 KiB (wide tile: no separate patches -- the turn of the immediate
-                                                                // quarters goes through the wave's first waiting slot, which is empty at a tile's end)
+    static constexpr int PATCH0 = WB0 + RING * WSTAGE;
+    static constexpr int RESQ = ONEACC ? 2 : NQ - 1;            // quarters of a finished tile that wait in LDS for their deferred epilogue (per wave)
+    static constexpr int RES0 = PATCH0 + (ONEACC ? 0 : 4 * 1024);  // four waves x RESQ x 4 KiB (one-accumulator tiles: no separate patches -- the turn of the
+                                                                // immediate quarters goes through the wave's first waiting slot, which is empty at a tile's end)
     static constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;
-    static constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;      // 157952 / 162048
+    static constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;      // 157952 (2, 2) | 162048 (4, 2) | 159488 (2, 4) | 108032 (2, 1)
+    static constexpr int UNITS_X = NG * XR * 18;                // staging units of a chunk: 8 channels x 4 pixels of one row (16 interior quads + 2 halo columns per row)
+    static constexpr int NU = (UNITS_X + 255) / 256;            // ... per staging thread (1 | 2)
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS");
 };
 }  // namespace f2
@@ -86,29 +99,31 @@ static unsigned f2_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ull
 // 1 = the h plane alone, ONE fp16 product per MAC with fp32 accumulation -- the reduced-precision bulk mode that mirrors the
 // reference's fp16 autocast sampler (/root/reference/sample_and_save.py:70, utils/option.py:49): same packing, same tiles,
 // the l plane is neither fetched, computed nor multiplied.
-template <int PRO, int NPLK, int MRK>
+template <int PRO, int NPLK, int MRK, int NRK>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
     static_assert(NPLK == 1 || NPLK == 2, "planes");
-    static_assert(MRK == 2 || MRK == 4, "row blocks per multiplying wave");
-    using GEO = Geo<MRK>;
-    constexpr int MR = MRK, COT = GEO::COT, WSTAGE = GEO::WSTAGE, RING = GEO::RING, WB0 = GEO::WB0, PATCH0 = GEO::PATCH0, RESQ = GEO::RESQ,
+    static_assert((MRK == 2 && (NRK == 2 || NRK == 4)) || (MRK == 4 && NRK == 2), "tile family");
+    using GEO = Geo<MRK, NRK>;
+    // (the tile's own geometry shadows x3's constants of the same names)
+    constexpr int MR = MRK, NR = NRK, TH = GEO::TH, XR = GEO::XR, XPL = GEO::XPL, XBYTES = GEO::XBYTES, NQ = GEO::NQ, NU = GEO::NU;
+    constexpr int COT = GEO::COT, WSTAGE = GEO::WSTAGE, RING = GEO::RING, WB0 = GEO::WB0, PATCH0 = GEO::PATCH0, RESQ = GEO::RESQ,
                   RES0 = GEO::RES0, ADTAB0 = GEO::ADTAB0;
-    // the cross products go to a second accumulator (scaled l planes) or, in the wide tile, to the same one (l planes at their true scale)
-    constexpr bool ACC2 = NPLK == 2 && MRK == 2;
-    constexpr bool LSCALED = MRK == 2;
-    // MRK == 2 -- NPLK == 2: 12 MFMAs per tap; 12 DMA pieces of 1 KiB per stage, three per stager.  NPLK == 1: 4 MFMAs per tap; the h
+    constexpr bool ONEACC = GEO::ONEACC;
+    // the cross products go to a second accumulator (scaled l planes) or, in the one-accumulator tiles, to the same one (l planes at their true scale)
+    constexpr bool ACC2 = NPLK == 2 && !ONEACC;
+    constexpr bool LSCALED = !ONEACC;
+    // MRK == 2 -- NPLK == 2: 12 DMA pieces of 1 KiB per stage, three per stager.  NPLK == 1: the h
     // plane is the first 6 pieces of a stage: stager w fetches pieces w and w + 2 (pieces 2 and 3 twice: harmless).
-    // MRK == 4 -- NPLK == 2: 24 MFMAs per tap, 24 pieces per stage, six per stager; NPLK == 1: 8 MFMAs, the h plane = 12 pieces, three per stager
+    // MRK == 4 -- NPLK == 2: 24 pieces per stage, six per stager; NPLK == 1: the h plane = 12 pieces, three per stager
+    // MFMAs per tap: 3 MR NR with both planes (6 | 12 | 24), MR NR with one
     constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = MRK == 2 ? (NPLK == 2 ? 3 : 2) : (NPLK == 2 ? 6 : 3);
-    constexpr int NL = 8;                         // global loads per chunk of raw pixels (the folded affine comes from an LDS table)
-    constexpr int PER_ITER = 3 * PPW + NL;        // VMEM operations a stager issues per chunk
-    // A weight stage must have landed when the barrier in front of its first read is reached; this many younger operations of the
+    // A weight stage must have landed when the barrier in front of its first read is reached; so many younger operations of the
     // stager may still be in flight then (vmcnt retires in order; the queue holds loads only).  Per iteration the queue is
-    //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw [NL] | #3
-    // RING == 4: the stage due at #1 is D1 of the previous iteration, at #2 its D2, at #3 this iteration's D0 -- 2 PPW + NL younger each time.
-    // RING == 3 (one segment less of flight): due at #1 is the previous D2 (raw, D0 younger), at #2 D0 (D1), at #3 D1 (D2, raw).
-    constexpr int NEWER1 = RING == 4 ? 2 * PPW + NL : NL + PPW, NEWER2 = RING == 4 ? 2 * PPW + NL : PPW, NEWER3 = RING == 4 ? 2 * PPW + NL : PPW + NL;
+    //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw [NL] | #3        NL = 8 global loads per staging unit of the iteration
+    // RING == 4: the stage due at #1 is D1 of the previous iteration, at #2 its D2, at #3 this iteration's D0 -- 2 PPW + NL' younger each time
+    // (NL': the previous iteration's pixel loads).
+    // RING == 3 (one segment less of flight): due at #1 is the previous D2 (raw', D0 younger), at #2 D0 (D1), at #3 D1 (D2, raw).
     static_assert(RING == 4 || RING == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
@@ -327,61 +342,68 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing may outlive the block
             return;
         }
-        // staging unit of this thread: one aligned quad (8 channels x 4 pixels) of one tile row (t4 < 192: interior quads;
-        // 192..215: the quad holding a halo column, the three pixels it does not need go to the dump column; 216..255
-        // repeat unit 215) -- see conv_bf16x3_stream_kernel
-        int s_row, s_g, s_col;
-        unsigned dsto[4];
-        if (t4 < 192) {
-            // 16 consecutive lanes = 4 quads x 2 channel groups x 2 rows: their 16-byte LDS entries of one pixel fall into 16
-            // different bank quartets (quad stride 64 B, group stride 6432 = 32 mod 256, row stride 1072 = 48 mod 256), so the
-            // ds_write_b128 of the transform is conflict-free; with 16 lanes on 16 consecutive quads it was a 4-way conflict
-            // that took LDS cycles from the multipliers' fragment reads (round-2 timeline: +20 % on two of three segments)
-            const int qd = ((t4 >> 2) & 3) | (((t4 >> 4) & 3) << 2);
-            s_g = t4 & 1;
-            s_row = ((t4 >> 6) << 1) | ((t4 >> 1) & 1);
-            s_col = qd * 4;
+        // Staging units: one aligned quad (8 channels x 4 pixels) of one tile row.  Units 0 .. 32 XR - 1 are the interior quads, the next
+        // 4 XR the quads holding a halo column (the three pixels they do not need go to the dump column), anything beyond repeats the
+        // last one -- see conv_bf16x3_stream_kernel.  Four-row tiles have 216 units, one per staging thread; the eight-row tile has 360:
+        // unit t4 for every thread, and a second one -- rows 8 and 9 (waves 4 / 6: one each per lane) or a halo column (waves 5 / 7) --
+        // that waves 4, 5 stage in the chunks of odd index and waves 6, 7 in those of even index: three units per stager and pair of chunks.
+        constexpr int U_INT = 32 * XR, U_HALO = 4 * XR;
+        int s_row[NU], s_g[NU], s_col[NU];
+        unsigned dsto[NU][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dsto[e] = (unsigned)(((s_g * XR + s_row) * XS + 1 + qd * 4 + e) * 16);
-        } else {
-            const int u = t4 - 192 < 24 ? t4 - 192 : 23;
-            s_row = u >> 2;
-            s_g = (u >> 1) & 1;
-            const bool right = u & 1;
-            s_col = right ? TW : -4;
-            const unsigned rowb = (unsigned)((s_g * XR + s_row) * XS);
+        for (int u = 0; u < NU; ++u) {
+            const int v = u == 0 ? t4 : 256 + (wave & 1) * 64 + lane;
+            if (v < U_INT) {
+                // 16 consecutive lanes = 4 quads x 2 channel groups x 2 rows: their 16-byte LDS entries of one pixel fall into 16
+                // different bank quartets (quad stride 64 B, group stride XR * 1072 = 32 | 224 mod 256, row stride 1072 = 48 mod 256), so the
+                // ds_write_b128 of the transform is conflict-free; with 16 lanes on 16 consecutive quads it was a 4-way conflict
+                // that took LDS cycles from the multipliers' fragment reads (round-2 timeline: +20 % on two of three segments)
+                const int qd = ((v >> 2) & 3) | (((v >> 4) & 3) << 2);
+                s_g[u] = v & 1;
+                s_row[u] = ((v >> 6) << 1) | ((v >> 1) & 1);
+                s_col[u] = qd * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dsto[e] = (rowb + (right ? (e == 0 ? XS - 2 : XS - 1) : (e == 3 ? 0 : XS - 1))) * 16;
+                for (int e = 0; e < 4; ++e) dsto[u][e] = (unsigned)(((s_g[u] * XR + s_row[u]) * XS + 1 + qd * 4 + e) * 16);
+            } else {
+                const int w = v - U_INT < U_HALO ? v - U_INT : U_HALO - 1;
+                s_row[u] = w >> 2;
+                s_g[u] = (w >> 1) & 1;
+                const bool right = w & 1;
+                s_col[u] = right ? TW : -4;
+                const unsigned rowb = (unsigned)((s_g[u] * XR + s_row[u]) * XS);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dsto[u][e] = (rowb + (right ? (e == 0 ? XS - 2 : XS - 1) : (e == 3 ? 0 : XS - 1))) * 16;
+            }
         }
 
         // ---- load cursor: the chunk whose pixels are fetched next (two to three chunks ahead of the multipliers) ----
         int l_item = 0, l_c = 0;
         const float* l_x0 = nullptr;
         const float* l_x1 = nullptr;
-        const float* l_aff = nullptr;
-        unsigned l_voff = 0;                         // this lane's byte offset inside a channel group's planes
-        const unsigned l_avoff = (unsigned)s_g * 64;  // ... and inside a chunk's (a, d) pairs
-        bool l_ok = false;
+        unsigned l_voff[NU];  // this lane's byte offset inside a channel group's planes (per unit)
+        bool l_ok[NU];
         bool l_edge = false;  // (wave-uniform) the tile touches the top or bottom image row: some lanes' rows are zero padding
         auto set_load_item = [&](int it) __attribute__((always_inline)) {
             int cot, b, th, tw;
             decode(it, cot, b, th, tw);
-            int gc = tw * TW + s_col;
-            if (gc < 0) gc += W;
-            if (gc >= W) gc -= W;  // azimuth is periodic
-            const int gr = th * TH + s_row - 1;
-            l_ok = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                int gc = tw * TW + s_col[u];
+                if (gc < 0) gc += W;
+                if (gc >= W) gc -= W;  // azimuth is periodic
+                const int gr = th * TH + s_row[u] - 1;
+                l_ok[u] = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
+                l_voff[u] = (unsigned)(s_g[u] * 8 * HW + (l_ok[u] ? gr * W + gc : 0)) * 4u;  // (16 HW floats < 2^31: launcher)
+            }
             l_edge = th == 0 || th == nTh - 1;
-            l_voff = (unsigned)(s_g * 8 * HW + (l_ok ? gr * W + gc : 0)) * 4u;  // (16 HW floats < 2^31: launcher)
             l_x0 = p.x.p0 + b * p.x.bs0;
             l_x1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
-            if (PRO != PRO_NONE) l_aff = reinterpret_cast<const float*>(p.aff) + (size_t)b * p.Cin * 2;
         };
         // Two register sets of raw pixels: the set filled in iteration q is transformed in iteration q+2.
         struct RawSet {
-            f32x4 raw[8];  // 8 channels x 4 pixels
-            bool ok;       // row inside the image
-            bool edge;     // wave-uniform: the tile has padding rows at all (interior tiles skip the masking)
+            f32x4 raw[NU][8];  // per unit: 8 channels x 4 pixels
+            bool ok[NU];       // row inside the image
+            bool edge;         // wave-uniform: the tile has padding rows at all (interior tiles skip the masking)
         };
         RawSet set0, set1;
         // The pixel loads are inline assembly, like the weight DMA: hipcc's own vmcnt bookkeeping cannot see the DMA, so a
@@ -395,12 +417,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         auto gload = [&](f32x4& d, const unsigned char* base, unsigned voff) __attribute__((always_inline)) {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
         };
-        auto load_next = [&](RawSet& r) __attribute__((always_inline)) {  // the cursor's chunk: NL loads; advances the cursor
+        // the cursor's chunk, units 0 .. NUR - 1: 8 loads each; advances the cursor
+        auto load_next = [&](RawSet& r, auto NUR) __attribute__((always_inline)) {
             const int ci0 = l_c * CK;
             const unsigned char* xq = sbase(ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW : l_x0 + (long)ci0 * HW);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) gload(r.raw[i], xq + (size_t)i * HW * 4, l_voff);
-            r.ok = l_ok;
+            for (int u = 0; u < decltype(NUR)::value; ++u) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gload(r.raw[u][i], xq + (size_t)i * HW * 4, l_voff[u]);
+                r.ok[u] = l_ok[u];
+            }
             r.edge = l_edge;
             if (l_c + 1 < nchunks)
                 ++l_c;
@@ -410,9 +436,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             }  // (past the end: the last chunk again, unused)
         };
         // wait until at most `newer` younger VMEM operations are in flight, then hand the set's registers to the compiler
-        auto use_set = [&](RawSet& r, auto NEWER) __attribute__((always_inline)) {
+        auto use_set = [&](RawSet& r, auto NUR, auto NEWER) __attribute__((always_inline)) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NEWER)::value) : "memory");
-            asm volatile("" : "+v"(r.raw[0]), "+v"(r.raw[1]), "+v"(r.raw[2]), "+v"(r.raw[3]), "+v"(r.raw[4]), "+v"(r.raw[5]), "+v"(r.raw[6]), "+v"(r.raw[7]));
+#pragma unroll
+            for (int u = 0; u < decltype(NUR)::value; ++u)
+                asm volatile("" : "+v"(r.raw[u][0]), "+v"(r.raw[u][1]), "+v"(r.raw[u][2]), "+v"(r.raw[u][3]), "+v"(r.raw[u][4]), "+v"(r.raw[u][5]), "+v"(r.raw[u][6]), "+v"(r.raw[u][7]));
         };
 
         // ---- the folded GroupNorm affine (a, d) of the tile's sample: Cin pairs in an LDS table, refreshed per tile ----
@@ -420,10 +448,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         // segment is bound by the CU's memory-instruction issue rate).  The table of tile T+1 is fetched into registers while
         // T's second-to-last chunk is transformed and written to LDS behind the transform of T's last chunk -- the block's
         // barrier #3 publishes it before the first chunk of T+1 is transformed.
-        f32x4 ad4[4];    // (a, d) of this thread's 8 channels of the chunk being transformed
-        f32x4 tab_v;     // table prefetch: pairs 2 t4, 2 t4 + 1 of the next tile's sample
-        int t_item = 0;  // tile whose table is in LDS
-        int x_c = 0;     // chunk (within its tile) that is transformed next
+        f32x4 ad4[NU][4];  // (a, d) of this thread's 8 channels of the chunk being transformed (per unit)
+        f32x4 tab_v;       // table prefetch: pairs 2 t4, 2 t4 + 1 of the next tile's sample
+        int t_item = 0;    // tile whose table is in LDS
+        int x_c = 0;       // chunk (within its tile) that is transformed next
         const f32x4* adtab = reinterpret_cast<const f32x4*>(smem + ADTAB0);
         const bool tab_lane = PRO != PRO_NONE && t4 * 2 < p.Cin;
         auto table_fetch = [&](int it) __attribute__((always_inline)) {  // one VMEM operation (asm: counted by hand like the others)
@@ -439,28 +467,28 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("" : "+v"(tab_v));
             if (tab_lane) *reinterpret_cast<f32x4*>(smem + ADTAB0 + t4 * 16) = tab_v;
         };
-        auto table_read = [&](bool ok, bool edge) __attribute__((always_inline)) {  // this thread's 8 channels of chunk x_c
+        auto table_read = [&](int u, bool ok, bool edge) __attribute__((always_inline)) {  // unit u's 8 channels of chunk x_c
             if (PRO == PRO_NONE) return;
-            const int j0 = (x_c * CK + s_g * 8) >> 1;
+            const int j0 = (x_c * CK + s_g[u] * 8) >> 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // zero padding of the ACTIVATED tensor: a = d = 0 gives silu(0) = 0
                 const f32x4 v = adtab[j0 + j];
-                ad4[j] = v;
-                if (edge) ad4[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                ad4[u][j] = v;
+                if (edge) ad4[u][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
 
         // ---- transform: affine, SiLU (same arithmetic as conv_bf16x3_pair_kernel), f16 split, pack ----
         unsigned xpk[2][NPLK][4];
-        auto xf = [&](RawSet& r, float& qv0, float& qv1, float& qm0, float& qm1, int k, int sl) __attribute__((always_inline)) {
+        auto xf = [&](RawSet& r, int u, float& qv0, float& qv1, float& qm0, float& qm1, int k, int sl) __attribute__((always_inline)) {
             const int e = k >> 2, i2 = k & 3, eo = e & 1;
             constexpr bool silu = PRO == PRO_AFFINE_SILU;
             if (sl == 0) {
-                qv0 = r.raw[2 * i2][e];
-                qv1 = r.raw[2 * i2 + 1][e];
+                qv0 = r.raw[u][2 * i2][e];
+                qv1 = r.raw[u][2 * i2 + 1][e];
                 if (PRO != PRO_NONE) {
-                    qv0 = qv0 * ad4[i2][0] + ad4[i2][1];
-                    qv1 = qv1 * ad4[i2][2] + ad4[i2][3];
+                    qv0 = qv0 * ad4[u][i2][0] + ad4[u][i2][1];
+                    qv1 = qv1 * ad4[u][i2][2] + ad4[u][i2][3];
                 }
 #ifdef R2DM_ACCURATE_SILU  // accuracy ablation (scripts/error_budget.py): libm exp + IEEE division instead of v_exp / v_rcp
             } else if (sl == 1) {
@@ -480,8 +508,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #endif
             } else if (sl == 6) {
                 if (PRO == PRO_NONE && r.edge) {
-                    qv0 = r.ok ? qv0 : 0.f;
-                    qv1 = r.ok ? qv1 : 0.f;
+                    qv0 = r.ok[u] ? qv0 : 0.f;
+                    qv1 = r.ok[u] ? qv1 : 0.f;
                 }
             } else if (sl == 7) {
 #ifdef F2_NO_XF  // timing ablation (wrong results)
@@ -497,131 +525,156 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #endif
             }
         };
-        // pixels 2*half, 2*half+1 of the thread's quad into x buffer `buf`
-        auto transform_half = [&](RawSet& r, int half, unsigned char* buf, bool from_table = true) __attribute__((always_inline)) {
-            float v0[2][4], v1[2][4], m0[2][4], m1[2][4];
-            if (half == 0 && from_table) table_read(r.ok, r.edge);
-            // both pixels stage by stage: eight independent dependency chains (16 values) per stage -- the stager shares its
-            // SIMD with a multiplier and cannot afford to wait for its own results (exp2 / rcp are quarter rate)
+        // pixels 2*half, 2*half+1 of the quads of units 0 .. NUR - 1 into x buffer `buf`
+        auto transform_half = [&](RawSet& r, auto NUR, int half, unsigned char* buf, bool from_table = true) __attribute__((always_inline)) {
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
+            for (int u = 0; u < decltype(NUR)::value; ++u) {
+                float v0[2][4], v1[2][4], m0[2][4], m1[2][4];
+                if (half == 0 && from_table) table_read(u, r.ok[u], r.edge);
+                // both pixels stage by stage: eight independent dependency chains (16 values) per stage -- the stager shares its
+                // SIMD with a multiplier and cannot afford to wait for its own results (exp2 / rcp are quarter rate)
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
 #ifdef F2_NO_XF
-                if (sl != 0 && sl != 7) continue;
+                    if (sl != 0 && sl != 7) continue;
 #endif
+#pragma unroll
+                    for (int eo = 0; eo < 2; ++eo)
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) xf(r, u, v0[eo][i2], v1[eo][i2], m0[eo][i2], m1[eo][i2], 4 * (2 * half + eo) + i2, sl);
+                }
 #pragma unroll
                 for (int eo = 0; eo < 2; ++eo)
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) xf(r, v0[eo][i2], v1[eo][i2], m0[eo][i2], m1[eo][i2], 4 * (2 * half + eo) + i2, sl);
+                    for (int pl = 0; pl < NPLK; ++pl)
+                        *reinterpret_cast<u32x4*>(buf + dsto[u][2 * half + eo] + pl * (XPL * 16)) =
+                            u32x4{xpk[eo][pl][0], xpk[eo][pl][1], xpk[eo][pl][2], xpk[eo][pl][3]};
             }
-#pragma unroll
-            for (int eo = 0; eo < 2; ++eo)
-#pragma unroll
-                for (int pl = 0; pl < NPLK; ++pl)
-                    *reinterpret_cast<u32x4*>(buf + dsto[2 * half + eo] + pl * (XPL * 16)) =
-                        u32x4{xpk[eo][pl][0], xpk[eo][pl][1], xpk[eo][pl][2], xpk[eo][pl][3]};
         };
 
-        // ---- prologue: ring stages 0..RING-2 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
-        // All 256 blocks start at once and the first pixels are a bandwidth burst (2 chunks x 32 KiB per CU = 16 MiB: 3-4 us of
-        // HBM; in-kernel timeline, profiles/r03_launch_overhead.txt), with the multipliers waiting at P.  So: what the first
-        // transform needs goes FIRST (the pixels of chunk 0, then this thread's (a, d) of chunk 0 -- read straight from global
-        // memory: the other waves' table writes are only published by P), everything else queues behind it (ring stages and table:
-        // L2 hits; the pixels of chunk 1), and the wait before the transform counts those as younger operations.
-        stamp(30);
-        set_load_item(0);
-        set_dma_item(0);
-        load_next(set0);
-        if (PRO != PRO_NONE) {
-            int cot0, b0, th0, tw0;
-            decode(0, cot0, b0, th0, tw0);
-            const unsigned char* a0 = sbase(reinterpret_cast<const float*>(p.aff) + (size_t)b0 * p.Cin * 2);
+        // N1 = staging units of this wave in the chunks of odd index (register set 1), N0 = in those of even index (set 0): 1 and 1 but
+        // for the eight-row tile (2 and 1 in waves 4, 5; 1 and 2 in waves 6, 7).  The hand-counted waits below depend on them.
+        auto run = [&](auto N1C, auto N0C) __attribute__((always_inline)) {
+            constexpr int NL1 = 8 * decltype(N1C)::value, NL0 = 8 * decltype(N0C)::value;
+            // ---- prologue: ring stages 0..RING-2 requested, chunk 0 in x buffer 0, the pixels of chunks 1 and 2 requested ----
+            // All 256 blocks start at once and the first pixels are a bandwidth burst (2 chunks x 32 KiB per CU = 16 MiB: 3-4 us of
+            // HBM; in-kernel timeline, profiles/r03_launch_overhead.txt), with the multipliers waiting at P.  So: what the first
+            // transform needs goes FIRST (the pixels of chunk 0, then this thread's (a, d) of chunk 0 -- read straight from global
+            // memory: the other waves' table writes are only published by P), everything else queues behind it (ring stages and table:
+            // L2 hits; the pixels of chunk 1), and the wait before the transform counts those as younger operations.
+            stamp(30);
+            set_load_item(0);
+            set_dma_item(0);
+            load_next(set0, N0C);
+            if (PRO != PRO_NONE) {
+                int cot0, b0, th0, tw0;
+                decode(0, cot0, b0, th0, tw0);
+                const unsigned char* a0 = sbase(reinterpret_cast<const float*>(p.aff) + (size_t)b0 * p.Cin * 2);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gload(ad4[j], a0 + 16 * j, (unsigned)s_g * 64u);
-        }
-        table_fetch(0);
-        stamp(31);
-        dma_stage(0, ic<0>{});
-        dma_stage(0, ic<1>{});
-        if constexpr (RING == 4) dma_stage(0, ic<2>{});
-        load_next(set1);  // (nchunks >= 4: the cursor stays inside the first tile)
-        constexpr int RING_NEWER = (RING - 1) * PPW;
-        use_set(set0, ic<RING_NEWER + NL>{});  // (ring stages and chunk 1 are younger)
-        stamp(32);
-        if (PRO != PRO_NONE) {
-            asm volatile("" : "+v"(ad4[0]), "+v"(ad4[1]), "+v"(ad4[2]), "+v"(ad4[3]));
+                for (int u = 0; u < decltype(N0C)::value; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ad4[j] = set0.ok ? ad4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        transform_half(set0, 0, smem, false);
-        transform_half(set0, 1, smem, false);
-        x_c = 1;
-        stamp(33);
-        table_store(ic<RING_NEWER + NL>{});  // (all stagers write their part of the first tile's table: published by P)
-        load_next(set0);                     // chunk 2 (the cursor saturates: harmless for a one-tile, two-chunk block)
-        // P needs the ring stages and this wave's x writes; the pixels of chunk 1 may still be on their way -- iteration 0 waits for
-        // them itself (the multipliers get to their first taps that much earlier)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NL) : "memory");
-        stamp(34);
-        __builtin_amdgcn_s_barrier();  // P
-        stamp(35);
-        asm volatile("" ::: "memory");
-
-        // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
-        // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
-        // stage sigma+RING, due RING-1 barriers later.  One stage is requested per segment, right behind the barrier that frees
-        // its slot:  D0(q) = stage 3q+RING-1, D1(q) = 3q+RING, D2(q) = 3q+RING+1.  A stage requested at the start of segment j
-        // must have landed at the end of segment j+RING-2 (NEWER1..3 younger operations may still fly).
-        // The pixels of chunk q+3 are requested in the third segment, into the register set emptied in the first two; they are
-        // transformed a whole iteration later (the other set holds chunk q+2 meanwhile).  VMEM queue of one iteration:
-        //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw(q+3) [NL] | #3
-        auto stage_iter = [&](int q, RawSet& cur) __attribute__((always_inline)) {
-            unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
-            const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
-            if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
-            dma_stage(3 * q, ic<RING - 1>{});    // D0
-            if (q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + PPW) : "memory");  // (only chunk 2 and D0 are younger than chunk 1)
-            use_set(cur, ic<PER_ITER + PPW>{});  // raw(q+1): requested two iterations ago
-            transform_half(cur, 0, nbuf);        // (past the end: the last chunk again, into the buffer nobody reads)
-            stamp(10);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER1) : "memory");  // stage 3q+1 landed
-            stamp(11);
-            __builtin_amdgcn_s_barrier();        // #1 = B'_{3q}
-            stamp(12);
-            asm volatile("" ::: "memory");
-            dma_stage(3 * q, ic<RING>{});        // D1
-            transform_half(cur, 1, nbuf);
-            stamp(13);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER2) : "memory");  // stage 3q+2 landed
-            stamp(14);
-            __builtin_amdgcn_s_barrier();        // #2 = B'_{3q+1}
-            stamp(15);
-            asm volatile("" ::: "memory");
-            if (last_of_tile) {                  // the next transform belongs to the next tile: its table (fetched at the start
-                table_store(ic<PER_ITER + 2 * PPW>{});  // of the previous iteration) goes to LDS
-                ++t_item;
+                    for (int j = 0; j < 4; ++j) gload(ad4[u][j], a0 + 16 * j, (unsigned)s_g[u] * 64u);
             }
-            x_c = last_of_tile ? 0 : x_c + 1;
-            dma_stage(3 * q, ic<RING + 1>{});    // D2
-            load_next(cur);                      // pixels of chunk q+3
-            stamp(16);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER3) : "memory");  // stage 3q+3 landed; this wave's x writes done
-            stamp(17);
-            __builtin_amdgcn_s_barrier();        // #3 = B'_{3q+2}: publishes x(q+1)
-            stamp(18);
+            table_fetch(0);
+            stamp(31);
+            dma_stage(0, ic<0>{});
+            dma_stage(0, ic<1>{});
+            if constexpr (RING == 4) dma_stage(0, ic<2>{});
+            load_next(set1, N1C);  // (nchunks >= 4: the cursor stays inside the first tile)
+            constexpr int RING_NEWER = (RING - 1) * PPW;
+            use_set(set0, N0C, ic<RING_NEWER + NL1>{});  // (ring stages and chunk 1 are younger)
+            stamp(32);
+            if (PRO != PRO_NONE) {
+#pragma unroll
+                for (int u = 0; u < decltype(N0C)::value; ++u) {
+                    asm volatile("" : "+v"(ad4[u][0]), "+v"(ad4[u][1]), "+v"(ad4[u][2]), "+v"(ad4[u][3]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ad4[u][j] = set0.ok[u] ? ad4[u][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            transform_half(set0, N0C, 0, smem, false);
+            transform_half(set0, N0C, 1, smem, false);
+            x_c = 1;
+            stamp(33);
+            table_store(ic<RING_NEWER + NL1>{});  // (all stagers write their part of the first tile's table: published by P)
+            load_next(set0, N0C);                 // chunk 2 (the cursor saturates: harmless for a one-tile, two-chunk block)
+            // P needs the ring stages and this wave's x writes; the pixels of chunk 1 may still be on their way -- iteration 0 waits for
+            // them itself (the multipliers get to their first taps that much earlier)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL1 + NL0) : "memory");
+            stamp(34);
+            __builtin_amdgcn_s_barrier();  // P
+            stamp(35);
             asm volatile("" ::: "memory");
+
+            // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
+            // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
+            // stage sigma+RING, due RING-1 barriers later.  One stage is requested per segment, right behind the barrier that frees
+            // its slot:  D0(q) = stage 3q+RING-1, D1(q) = 3q+RING, D2(q) = 3q+RING+1.  A stage requested at the start of segment j
+            // must have landed at the end of segment j+RING-2 (NEWER1..3 younger operations may still fly).
+            // The pixels of chunk q+3 are requested in the third segment, into the register set emptied in the first two; they are
+            // transformed a whole iteration later (the other set holds chunk q+2 meanwhile).  VMEM queue of one iteration:
+            //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw(q+3) [NLc] | #3          (NLc: this iteration's set, NLp: the other one's)
+            auto stage_iter = [&](int q, RawSet& cur, auto NCUR, auto NPREV) __attribute__((always_inline)) {
+                constexpr int NLc = 8 * decltype(NCUR)::value, NLp = 8 * decltype(NPREV)::value;
+                constexpr int NEWER1 = RING == 4 ? 2 * PPW + NLp : NLp + PPW, NEWER2 = RING == 4 ? 2 * PPW + NLp : PPW,
+                              NEWER3 = RING == 4 ? 2 * PPW + NLc : PPW + NLc;
+                unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
+                const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
+                if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
+                dma_stage(3 * q, ic<RING - 1>{});    // D0
+                if (q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLp + PPW) : "memory");  // (only chunk 2 and D0 are younger than chunk 1)
+                use_set(cur, NCUR, ic<4 * PPW + NLp>{});  // raw(q+1): requested two iterations ago (the previous iteration's queue and D0 are younger)
+                transform_half(cur, NCUR, 0, nbuf);       // (past the end: the last chunk again, into the buffer nobody reads)
+                stamp(10);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER1) : "memory");  // stage 3q+1 landed
+                stamp(11);
+                __builtin_amdgcn_s_barrier();        // #1 = B'_{3q}
+                stamp(12);
+                asm volatile("" ::: "memory");
+                dma_stage(3 * q, ic<RING>{});        // D1
+                transform_half(cur, NCUR, 1, nbuf);
+                stamp(13);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER2) : "memory");  // stage 3q+2 landed
+                stamp(14);
+                __builtin_amdgcn_s_barrier();        // #2 = B'_{3q+1}
+                stamp(15);
+                asm volatile("" ::: "memory");
+                if (last_of_tile) {                  // the next transform belongs to the next tile: its table (fetched at the start
+                    table_store(ic<5 * PPW + NLp>{});  // of the previous iteration) goes to LDS
+                    ++t_item;
+                }
+                x_c = last_of_tile ? 0 : x_c + 1;
+                dma_stage(3 * q, ic<RING + 1>{});    // D2
+                load_next(cur, NCUR);                // pixels of chunk q+3
+                stamp(16);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER3) : "memory");  // stage 3q+3 landed; this wave's x writes done
+                stamp(17);
+                __builtin_amdgcn_s_barrier();        // #3 = B'_{3q+2}: publishes x(q+1)
+                stamp(18);
+                asm volatile("" ::: "memory");
+            };
+            for (int q = 0; q < Q; q += 2) {  // (Q is even: chunks per tile are)
+                stage_iter(q, set1, N1C, N0C);
+                stage_iter(q + 1, set0, N0C, N1C);
+            }
         };
-        for (int q = 0; q < Q; q += 2) {  // (Q is even: chunks per tile are)
-            stage_iter(q, set1);
-            stage_iter(q + 1, set0);
+        if constexpr (NU == 1) {
+            run(ic<1>{}, ic<1>{});
+        } else {
+            if (wave < 2) run(ic<2>{}, ic<1>{});
+            else run(ic<1>{}, ic<2>{});
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing may outlive the block
         return;
     }
 
     // ============================================= multiplier waves =============================================
-    unsigned xb0[NR], xb1[NR];  // fragment addresses in x buffer 0 / 1
+    // fragment addresses in x buffer 0 / 1.  The eight-row tile keeps ONE address per buffer (its four segments are constant offsets from
+    // the first: they go into the instruction's offset field -- eight address registers were what pushed that tile into spilling)
+    constexpr int NXB = NR == 4 ? 1 : NR;
+    unsigned xb0[NXB], xb1[NXB];
 #pragma unroll
-    for (int n = 0; n < NR; ++n) {
+    for (int n = 0; n < NXB; ++n) {
         const int s = wave * NR + n;
         xb0[n] = lds0 + (unsigned)(((hi * XR + (s >> 1)) * XS + (s & 1) * 32 + l31) * 16);
         xb1[n] = xb0[n] + XBYTES;
@@ -642,8 +695,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     // Fragments of one tap: the l plane is used by the first two products only and is single-buffered -- the next tap's is
     // read as soon as its last product has been issued; the h plane is needed up to the last product and is double-buffered.
     u32x4 fa0[2][MR], fb0[2][NR], fa1[MR], fb1[NR];
+    constexpr int NOPS = MR + NR;  // operands of a tap per plane: A (weights) 0 .. MR - 1, B (pixels) MR .. MR + NR - 1
     // read of plane PL, operand WW (A m0, A m1, B n0, B n1) of tap (ky, tx); plane 0 goes to buffer NB
-    auto frag_rd = [&](const unsigned (&xb)[NR], unsigned wb, auto KY, auto TX, auto PL, auto WW, auto NB) __attribute__((always_inline)) {
+    auto frag_rd = [&](const unsigned (&xb)[NXB], unsigned wb, auto KY, auto TX, auto PL, auto WW, auto NB) __attribute__((always_inline)) {
         constexpr int ky = decltype(KY)::value, tx = decltype(TX)::value, pl = decltype(PL)::value, w = decltype(WW)::value;
         constexpr int nb = decltype(NB)::value;
         if constexpr (w < MR) {
@@ -651,26 +705,32 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(wb), "i"(pl * (3 * NG * COT * 16) + tx * (NG * COT * 16) + w * 512));
         } else {
             u32x4& d = pl == 0 ? fb0[nb][w - MR] : fb1[w - MR];
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(xb[w - MR]), "i"(pl * (XPL * 16) + ky * (XS * 16) + tx * 16));
+            constexpr int n = w - MR, seg = NXB == 1 ? ((n >> 1) * XS + (n & 1) * 32) * 16 : 0;  // (segment n of the wave: row n / 2, columns 32 (n % 2) ...)
+            static_assert(XPL * 16 + 2 * (XS * 16) + 2 * 16 + 3 * XS * 16 < 65536, "ds_read offset field");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(xb[NXB == 1 ? 0 : n]), "i"(pl * (XPL * 16) + ky * (XS * 16) + tx * 16 + seg));
         }
     };
     // all fragments of a tap (0, 0) at once, in the order the taps read them: plane 0 (into h buffer NB), then plane 1
-    auto frag_all = [&](const unsigned (&xb)[NR], unsigned wb, auto NB) __attribute__((always_inline)) {
+    auto frag_all = [&](const unsigned (&xb)[NXB], unsigned wb, auto NB) __attribute__((always_inline)) {
         auto f = [&](auto PL, auto WW) __attribute__((always_inline)) { frag_rd(xb, wb, ic<0>{}, ic<0>{}, PL, WW, NB); };
-        f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{}); f(ic<0>{}, ic<3>{});
-        if constexpr (MR == 4) { f(ic<0>{}, ic<4>{}); f(ic<0>{}, ic<5>{}); }
+        f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{});
+        if constexpr (NOPS >= 4) f(ic<0>{}, ic<3>{});
+        if constexpr (NOPS == 6) { f(ic<0>{}, ic<4>{}); f(ic<0>{}, ic<5>{}); }
         if constexpr (NPLK == 2) {
-            f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
-            if constexpr (MR == 4) { f(ic<1>{}, ic<4>{}); f(ic<1>{}, ic<5>{}); }
+            f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{});
+            if constexpr (NOPS >= 4) f(ic<1>{}, ic<3>{});
+            if constexpr (NOPS == 6) { f(ic<1>{}, ic<4>{}); f(ic<1>{}, ic<5>{}); }
         }
     };
     auto frag_first = [&](unsigned wb) __attribute__((always_inline)) {
         auto f = [&](auto PL, auto WW) __attribute__((always_inline)) { frag_rd(xb0, wb, ic<0>{}, ic<0>{}, PL, WW, ic<0>{}); };
-        f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{}); f(ic<0>{}, ic<3>{});
-        if constexpr (MR == 4) { f(ic<0>{}, ic<4>{}); f(ic<0>{}, ic<5>{}); }
+        f(ic<0>{}, ic<0>{}); f(ic<0>{}, ic<1>{}); f(ic<0>{}, ic<2>{});
+        if constexpr (NOPS >= 4) f(ic<0>{}, ic<3>{});
+        if constexpr (NOPS == 6) { f(ic<0>{}, ic<4>{}); f(ic<0>{}, ic<5>{}); }
         if constexpr (NPLK == 2) {
-            f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{}); f(ic<1>{}, ic<3>{});
-            if constexpr (MR == 4) { f(ic<1>{}, ic<4>{}); f(ic<1>{}, ic<5>{}); }
+            f(ic<1>{}, ic<0>{}); f(ic<1>{}, ic<1>{}); f(ic<1>{}, ic<2>{});
+            if constexpr (NOPS >= 4) f(ic<1>{}, ic<3>{});
+            if constexpr (NOPS == 6) { f(ic<1>{}, ic<4>{}); f(ic<1>{}, ic<5>{}); }
         }
     };
 
@@ -697,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             stamp(4 + ky);
             asm volatile("" ::: "memory");
         } else if (NPLK == 2) {
-            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");  // (everything but xl': NR reads)
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one plane: all four fragments of this tap)
         }
@@ -738,11 +798,19 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (i == 1) fr(ic<0>{}, ic<1>{});
             if (i == 2) fr(ic<0>{}, ic<2>{});
             if (i == 3) fr(ic<0>{}, ic<3>{});
-            if constexpr (MR == 4) {
+            if constexpr (NOPS == 6) {
                 if (i == 4) fr(ic<0>{}, ic<4>{});
                 if (i == 5) fr(ic<0>{}, ic<5>{});
             }
-            if constexpr (NPLK == 2 && MR == 2) {
+            if constexpr (NPLK == 2 && MR == 2 && NR == 4) {
+                if (i == 8) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 7)
+                if (i == 9) fr(ic<1>{}, ic<1>{});
+                if (i == 16) fr(ic<1>{}, ic<2>{});  // xl' (its last product was unit 15)
+                if (i == 17) fr(ic<1>{}, ic<3>{});
+                if (i == 18) fr(ic<1>{}, ic<4>{});
+                if (i == 19) fr(ic<1>{}, ic<5>{});
+            }
+            if constexpr (NPLK == 2 && MR == 2 && NR == 2) {
                 if (i == 4) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 3)
                 if (i == 5) fr(ic<1>{}, ic<1>{});
                 if (i == 8) fr(ic<1>{}, ic<2>{});  // xl' (its last product was unit 7)
@@ -771,8 +839,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     using gcf = const float __attribute__((address_space(1)))*;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
     using gf4 = f32x4 __attribute__((address_space(1)))*;
-    constexpr int SEGW = TW / 32, NQ = MR * NR;
-    static_assert(MRK != 2 || (NQ == 4 && RESQ == 3), "three deferred quarters in the former residual area");
+    constexpr int SEGW = TW / 32;
+    static_assert(ONEACC || (NQ == 4 && RESQ == 3), "three deferred quarters in the former residual area");
     float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
     f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
     float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
@@ -782,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     const float sc_blk = p.scale ? *(gcf)p.scale : 1.0f;
     const float wsc = p.wscale ? *(gcf)p.wscale : 1.0f;  // inverse of the packer's power-of-two weight scale (exact)
     float* const dump = reinterpret_cast<float*>(smem + RES0) + wave * (RESQ * 1024);
-    float* const patch = MRK == 2 ? reinterpret_cast<float*>(smem + PATCH0) + wave * 256 : dump;
+    float* const patch = !ONEACC ? reinterpret_cast<float*>(smem + PATCH0) + wave * 256 : dump;
     auto fresh_lane = [&]() __attribute__((always_inline)) {  // (per-lane constants must not be hoisted across the MFMA stream)
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -833,7 +901,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             st_s[k8] = (double)s0[k8] + (double)s1[k8];
             st_q[k8] = (double)q0[k8] + (double)q1[k8];
         }
-        epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * COT + decltype(M)::value * 32, wave, ln);
+        // M = index of a pair of quarters (2 M, 2 M + 1): one image row of one 32-channel half -- a statistics slot.  Four-row tiles: the
+        // half is M, the slot (tile, wave).  The eight-row tile's wave owns rows 2 wave, 2 wave + 1: half M / 2, and the slot is the one the
+        // four-row tiling gives that row -- tile row 2 th + wave / 2, "wave" 2 (wave % 2) + M % 2: same slots, same sums, same order.
+        constexpr int mm = decltype(M)::value;
+        if constexpr (NR == 4) epi_stat_write_bfly8(p, st_s, st_q, b, 2 * th + (wave >> 1), tw, nTw, cot * COT + (mm >> 1) * 32, 2 * (wave & 1) + (mm & 1), ln);
+        else epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * COT + mm * 32, wave, ln);
     };
     auto range_flush = [&](int ln) __attribute__((always_inline)) {
         if (!p.range) return;
@@ -870,21 +943,25 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         if constexpr (decltype(PAR)::value == 1) {
             if (e_c == nchunks - 1) {  // the tile's last chunk: its biases and the first quarter's residual are requested now
                 const int ln = fresh_lane();
-                if constexpr (MRK == 2) {  // (the wide tile has no registers to hold 16 biases through a chunk: requested at the tile's end)
+                if constexpr (!ONEACC) {  // (the one-accumulator tiles have no registers to hold their biases through a chunk: requested at the tile's end)
 #pragma unroll
                     for (int m = 0; m < MR; ++m)
 #pragma unroll
                         for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = ((gcf)p.bias)[e_cot * COT + m * 32 + k8 * 8 + (ln >> 3)];
                 }
-                res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
+                // (the eight-row tile cannot hold 16 residual registers through a chunk -- as loads here they were spilled one by one behind
+                // vmcnt(0): its first quarter's residual is requested at the tile's end, in front of the biases that quarter waits for anyway)
+                if constexpr (NR != 4) res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
             }
         }
         tap(q, ic<0>{}, PAR); tap(q, ic<1>{}, PAR); tap(q, ic<2>{}, PAR);
         tap(q, ic<3>{}, PAR); tap(q, ic<4>{}, PAR); tap(q, ic<5>{}, PAR);
         tap(q, ic<6>{}, PAR); tap(q, ic<7>{}, PAR); tap(q, ic<8>{}, PAR);
         ++e_c;
-        if constexpr (MRK == 4) {
-            // ---- 128-channel tile: ONE accumulator per MFMA tile, eight quarters (m, n) per wave.  Six are finished at the tile's end, the
+        if constexpr (ONEACC) {
+            // ---- 128-channel tile and eight-row tile: ONE accumulator per MFMA tile, eight quarters (m, n) per wave, numbered qd = m NR + n, in pairs
+            // (2 M, 2 M + 1) that share a statistics slot (128 channels: row block M, both 32-pixel segments of the wave's row; eight rows: row
+            // block M / 2, the wave's row M % 2).  Six are finished at the tile's end, the
             // last row block's two (6, 7) wait, turned, in 32 KiB of LDS and are finished behind the next tile's first two chunks (the
             // multipliers bound a chunk of this tile -- 24 MFMAs per tap -- so a deferred quarter costs what it takes; at the tile's end all
             // four stagers and the matrix pipe wait).  Biases are requested at the tile's end, one row block ahead (the loop has no
@@ -914,13 +991,22 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 range_flush(ln);
                 pending = false;
             };
+            // The eight-row tile finishes all eight quarters at the tile's end: with a residual held for a waiting row block through the next
+            // tile's first chunk it spilled twelve of those registers, each behind vmcnt(0); the multipliers bound a chunk of these tiles, so
+            // a deferred quarter costs what it takes wherever it runs.
+            constexpr bool DEFER_ROWBLOCK = NR != 4;
             if constexpr (decltype(PAR)::value == 0) {
-                if (pending && e_c == 1) {
+                if (DEFER_ROWBLOCK && pending && e_c == 1) {
                     // the next chunk's first fragments (72 registers, prefetched by tap 8) are dropped for the slice and read again behind
                     // it: with them alive the slice spilled fragments around itself
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    asm volatile("" : "=v"(fa0[1][0]), "=v"(fa0[1][1]), "=v"(fa0[1][2]), "=v"(fa0[1][3]), "=v"(fb0[1][0]), "=v"(fb0[1][1]));
-                    asm volatile("" : "=v"(fa1[0]), "=v"(fa1[1]), "=v"(fa1[2]), "=v"(fa1[3]), "=v"(fb1[0]), "=v"(fb1[1]));
+                    if constexpr (MR == 4) {
+                        asm volatile("" : "=v"(fa0[1][0]), "=v"(fa0[1][1]), "=v"(fa0[1][2]), "=v"(fa0[1][3]), "=v"(fb0[1][0]), "=v"(fb0[1][1]));
+                        asm volatile("" : "=v"(fa1[0]), "=v"(fa1[1]), "=v"(fa1[2]), "=v"(fa1[3]), "=v"(fb1[0]), "=v"(fb1[1]));
+                    } else {
+                        asm volatile("" : "=v"(fa0[1][0]), "=v"(fa0[1][1]), "=v"(fb0[1][0]), "=v"(fb0[1][1]), "=v"(fb0[1][2]), "=v"(fb0[1][3]));
+                        asm volatile("" : "=v"(fa1[0]), "=v"(fa1[1]), "=v"(fb1[0]), "=v"(fb1[1]), "=v"(fb1[2]), "=v"(fb1[3]));
+                    }
                     f32x4 rv7[4] = {};
                     slice_w(rv_e, rv7, ic<1>{});
                     frag_all(xb1, lds_w0, ic<1>{});  // (chunk q + 1: x buffer 1, stage 3 (q + 1) in ring slot 0, h buffer 1)
@@ -932,18 +1018,25 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     stamp(7);
                     const int ln = fresh_lane();
                     const int l31e = ln & 31, hie = ln >> 5;
-                    const bool last_tile = e_item + 1 == nIt;
+                    const bool last_tile = !DEFER_ROWBLOCK || e_item + 1 == nIt;
                     auto bias_request = [&](auto M) __attribute__((always_inline)) {
                         constexpr int m = decltype(M)::value;
 #pragma unroll
                         for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = ((gcf)p.bias)[e_cot * COT + m * 32 + k8 * 8 + (ln >> 3)];
                     };
+                    // (eight-row tile: nothing of the epilogue lives through the MFMA loop -- its first residual buffer is local to the tile's end;
+                    // rv_e, which must keep its zeros for launches without a residual, costs the other tiles 16 registers all along)
+                    f32x4 rv0l[4] = {};
+                    auto& rvA = [&]() -> f32x4 (&)[4] { if constexpr (NR == 4) return rv0l; else return rv_e; }();
+                    if constexpr (NR == 4) res_request_to(rvA, ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
                     bias_request(ic<0>{});
-                    bias_request(ic<1>{});
+                    bias_request(ic<1>{});  // (the eight-row tile has two row blocks: all of its biases)
                     f32x4 rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
                     res_request_to(rv1, ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
                     res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
-                    res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                    // (eight-row tile: the fourth buffer is requested behind quarter 0, whose accumulator registers it takes -- requested here it
+                    // was spilled behind vmcnt(0))
+                    if constexpr (NR != 4) res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
                     auto do_q = [&](auto QD, f32x4 (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
                         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
                         f32x4 t[4];
@@ -957,23 +1050,24 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     };
                     float ps0[4], pq0[4], ps1[4], pq1[4];
                     stamp(20);
-                    do_q(ic<0>{}, rv_e, ps0, pq0);
+                    do_q(ic<0>{}, rvA, ps0, pq0);
                     stamp(21);
-                    res_request_to(rv_e, ic<4>{}, e_b, e_th, e_tw, e_cot, ln);
+                    if constexpr (NR == 4) res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                    res_request_to(rvA, ic<4>{}, e_b, e_th, e_tw, e_cot, ln);
                     do_q(ic<1>{}, rv1, ps1, pq1);
                     stamp(22);
                     res_request_to(rv1, ic<5>{}, e_b, e_th, e_tw, e_cot, ln);
                     half_stats(ic<0>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
                     stamp(23);
-                    bias_request(ic<2>{});
+                    if constexpr (MR == 4) bias_request(ic<2>{});
                     do_q(ic<2>{}, rv2, ps0, pq0);
                     stamp(24);
                     if (last_tile) res_request_to(rv2, ic<6>{}, e_b, e_th, e_tw, e_cot, ln);  // (nothing left to hide the waiting quarters behind)
                     do_q(ic<3>{}, rv3, ps1, pq1);
                     if (last_tile) res_request_to(rv3, ic<7>{}, e_b, e_th, e_tw, e_cot, ln);
                     half_stats(ic<1>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
-                    bias_request(ic<3>{});
-                    do_q(ic<4>{}, rv_e, ps0, pq0);
+                    if constexpr (MR == 4) bias_request(ic<3>{});
+                    do_q(ic<4>{}, rvA, ps0, pq0);
                     do_q(ic<5>{}, rv1, ps1, pq1);
                     half_stats(ic<2>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
                     // the last row block waits in LDS (the patch -- the first KiB of slot 0 -- is free now: LDS operations of a wave are in order)
@@ -989,8 +1083,13 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         res_request(ic<6>{}, e_b, e_th, e_tw, e_cot, ln);
                     }
                     // (the accumulators restart from C = 0 in the next tile's first products: end the old values' lives)
-                    asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
-                    asm volatile("" : "=v"(acc[2][0]), "=v"(acc[2][1]), "=v"(acc[3][0]), "=v"(acc[3][1]));
+                    if constexpr (MR == 4) {
+                        asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
+                        asm volatile("" : "=v"(acc[2][0]), "=v"(acc[2][1]), "=v"(acc[3][0]), "=v"(acc[3][1]));
+                    } else {
+                        asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[0][2]), "=v"(acc[0][3]));
+                        asm volatile("" : "=v"(acc[1][0]), "=v"(acc[1][1]), "=v"(acc[1][2]), "=v"(acc[1][3]));
+                    }
                     if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
                     frag_first(lds_w0);  // (stage 3 (q + 1): ring slot 0)
                 }
@@ -1128,24 +1227,38 @@ static int f2_cu_count() {
     return v;
 }
 
-// 3x3, whole 4 x 64 pixel tiles (the wide epilogue has no pixel predication), 64- (or 128-) channel output tiles, 64 <= Cin <= 512 in
+// 3x3, whole px_rows x 64 pixel tiles (the wide epilogue has no pixel predication), 64- (or 128-) channel output tiles, 64 <= Cin <= 512 in
 // multiples of 64 (an even number of 16-channel chunks, at least four; the (a, d) table), a concat seam on a chunk boundary.
-bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile) {
-    return taps == 9 && (co_tile == 64 || co_tile == 128) && Cout % co_tile == 0 && Cin % (4 * f2::CK) == 0 && Cin * 8 <= f2::ADTAB_BYTES &&
-           H % f2::TH == 0 && W % f2::TW == 0 && H * (long)W * 16 < (1L << 31);
+// Tiles (co_tile x px_rows): 64 x 4 (two accumulators), 128 x 4 and 64 x 8 (one).
+bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile, int px_rows) {
+    const bool tile_ok = (co_tile == 64 && (px_rows == 4 || px_rows == 8)) || (co_tile == 128 && px_rows == 4);
+    return taps == 9 && tile_ok && Cout % co_tile == 0 && Cin % (4 * f2::CK) == 0 && Cin * 8 <= f2::ADTAB_BYTES &&
+           H % px_rows == 0 && W % f2::TW == 0 && H * (long)W * 16 < (1L << 31);
 }
 
 long conv_f16x2_packed_floats(int Cin, int Cout) { return (long)Cout * Cin * 9 * f2::NPL / 2; }
 
-int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch) {
-    const bool wide_ok = conv_f16x2_supported(Cin, Cout, 9, H, W, 128);
-    if (const char* e = getenv("R2DM_F2_CO_TILE")) return atoi(e) == 128 && wide_ok ? 128 : 64;  // (read per call: per-kernel tests switch it)
-    // The one-accumulator tile takes three truncating accumulator updates per tap where the 64-channel tile takes one.  Measured per layer
-    // against fp64 (tests/test_hip_kernels.py::test_conv3x3_both_operand_splits): its rms error is 0.4-0.6x a plain fp32 fmaf chain's (the
+int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_batch, int* px_rows) {
+    const bool wide_ok = conv_f16x2_supported(Cin, Cout, 9, H, W, 128, 4), tall_ok = conv_f16x2_supported(Cin, Cout, 9, H, W, 64, 8);
+    int rows_dummy;
+    int& rows = px_rows ? *px_rows : rows_dummy;
+    rows = 4;
+    if (const char* e = getenv("R2DM_F2_CO_TILE")) {  // "64" | "128" | "64x8" (read per call: per-kernel tests switch it)
+        if (atoi(e) == 128 && wide_ok) return 128;
+        if (strstr(e, "x8") && tall_ok && px_rows) rows = 8;
+        return 64;
+    }
+    // The one-accumulator tiles take three truncating accumulator updates per tap where the 64 x 4 tile takes one.  Measured per layer
+    // against fp64 (tests/test_hip_kernels.py::test_conv3x3_both_operand_splits): their rms error is 0.4-0.6x a plain fp32 fmaf chain's (the
     // fp32-MFMA kernel with one accumulator) at every depth, 0.66-0.70x the library's fp32 kernel at Cin <= 128, 1.2x at Cin = 256 and 1.7x at
-    // Cin = 512, where that kernel accumulates on two levels.  Used up to Cin = 256 (R2DM_F2_WIDE_MAX_CIN: experiments).
+    // Cin = 512, where that kernel accumulates on two levels.  Used up to Cin = 256 (R2DM_F2_WIDE_MAX_CIN: experiments), where the launch
+    // still has a tile per CU at the planned batch: 128 x 4 for layers with >= 128 output channels, else 64 x 8 (R2DM_F2_TALL=0: never).
     static const int max_cin = getenv("R2DM_F2_WIDE_MAX_CIN") ? atoi(getenv("R2DM_F2_WIDE_MAX_CIN")) : 256;
-    return wide_ok && Cin <= max_cin && (pixels_times_batch / (f2::TH * f2::TW)) * (Cout / 128) >= f2_cu_count() ? 128 : 64;
+    static const bool tall_on = !getenv("R2DM_F2_TALL") || atoi(getenv("R2DM_F2_TALL")) != 0;
+    const long px_tiles = pixels_times_batch / (4 * f2::TW);
+    if (wide_ok && Cin <= max_cin && px_tiles * (Cout / 128) >= f2_cu_count()) return 128;
+    if (tall_ok && tall_on && px_rows && Cin <= max_cin && (px_tiles / 2) * (Cout / 64) >= f2_cu_count()) rows = 8;
+    return 64;
 }
 
 // max_bits <- float bits of max|w[0 .. n)| (non-negative floats order like their bit patterns; NaN sorts above infinity)
@@ -1170,22 +1283,23 @@ hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale, int co_tile) {
-    if ((co_tile != 64 && co_tile != 128) || Cout % co_tile) return hipErrorInvalidValue;
+hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale, int co_tile, int px_rows) {
+    if ((co_tile != 64 && co_tile != 128) || Cout % co_tile || (px_rows != 4 && !(px_rows == 8 && co_tile == 64))) return hipErrorInvalidValue;
     const long total = (long)Cout * Cin * 9 * f2::NPL;
     if (wscale) {
         hipError_t e = launch_weight_absmax(w, (long)Cout * Cin * 9, reinterpret_cast<int*>(wscale), s);
         if (e != hipSuccess) return e;
     }
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale, co_tile, co_tile == 64);
+    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale, co_tile, co_tile == 64 && px_rows == 4);  // (the one-accumulator tiles: l planes at their true scale)
     return hipGetLastError();
 }
 
-template <int PRO, int NPLK, int MRK>
+template <int PRO, int NPLK, int MRK, int NRK>
 static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
-    auto kern = conv_f16x2_kernel<PRO, NPLK, MRK>;
-    constexpr int LDS_TOTAL = f2::Geo<MRK>::LDS_TOTAL, COT = f2::Geo<MRK>::COT;
+    auto kern = conv_f16x2_kernel<PRO, NPLK, MRK, NRK>;
+    using GEO = f2::Geo<MRK, NRK>;
+    constexpr int LDS_TOTAL = GEO::LDS_TOTAL, COT = GEO::COT;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
@@ -1195,7 +1309,7 @@ static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
     static const bool one_tile_blocks = getenv("R2DM_F2_NONPERSISTENT") != nullptr;  // experiments: one tile per block
     const int n_cu = f2_cu_count();
     const unsigned grid = (unsigned)(tiles < n_cu || one_tile_blocks ? tiles : n_cu);
-    const int nCoT = p.Cout / COT, nTw = p.W / f2::TW, nTh = p.H / f2::TH;
+    const int nCoT = p.Cout / COT, nTw = p.W / f2::TW, nTh = p.H / GEO::TH;
     const int dmax = nCoT > nTw ? (nCoT > nTh ? nCoT : nTh) : (nTw > nTh ? nTw : nTh);
     if (tiles * dmax >= (1ll << 32)) return hipErrorInvalidValue;  // (F2Div is exact below that)
     const F2Div dv{f2_magic(nCoT), f2_magic(nTw), f2_magic(nTh)};
@@ -1203,36 +1317,37 @@ static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int MRK>
+template <int MRK, int NRK>
 static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
-    const long tiles = (long)(p.Cout / f2::Geo<MRK>::COT) * (p.W / f2::TW) * (p.H / f2::TH) * p.B;
-    if constexpr (MRK == 2) {  // pre-split input (presplit.hip): 64-channel tiles only
-        if (p.prologue == PRO_PRESPLIT) return p.pieces == 1 ? launch_f2<PRO_PRESPLIT, 1, 2>(p, tiles, s) : launch_f2<PRO_PRESPLIT, 2, 2>(p, tiles, s);
+    using GEO = f2::Geo<MRK, NRK>;
+    const long tiles = (long)(p.Cout / GEO::COT) * (p.W / f2::TW) * (p.H / GEO::TH) * p.B;
+    if constexpr (MRK == 2 && NRK == 2) {  // pre-split input (presplit.hip): 64 x 4 tiles only
+        if (p.prologue == PRO_PRESPLIT) return p.pieces == 1 ? launch_f2<PRO_PRESPLIT, 1, 2, 2>(p, tiles, s) : launch_f2<PRO_PRESPLIT, 2, 2, 2>(p, tiles, s);
     }
     if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
         switch (p.prologue) {
-            case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK>(p, tiles, s);
-            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 1, MRK>(p, tiles, s);
-            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 1, MRK>(p, tiles, s);
+            case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK, NRK>(p, tiles, s);
+            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 1, MRK, NRK>(p, tiles, s);
+            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 1, MRK, NRK>(p, tiles, s);
         }
     }
     switch (p.prologue) {
-        case PRO_NONE: return launch_f2<PRO_NONE, 2, MRK>(p, tiles, s);
-        case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2, MRK>(p, tiles, s);
-        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2, MRK>(p, tiles, s);
+        case PRO_NONE: return launch_f2<PRO_NONE, 2, MRK, NRK>(p, tiles, s);
+        case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2, MRK, NRK>(p, tiles, s);
+        case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2, MRK, NRK>(p, tiles, s);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
-    if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile)) return hipErrorInvalidValue;
+    if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile, p.px_rows)) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr) return hipErrorInvalidValue;
-    if (p.prologue == PRO_PRESPLIT && (p.co_tile != 64 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
+    if (p.prologue == PRO_PRESPLIT && (p.co_tile != 64 || p.px_rows != 4 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
 #ifndef F2_PROF
     if (p.prof != nullptr) return hipErrorInvalidValue;
 #endif
-    return p.co_tile == 128 ? launch_f2_tile<4>(p, s) : launch_f2_tile<2>(p, s);
+    return p.co_tile == 128 ? launch_f2_tile<4, 2>(p, s) : p.px_rows == 8 ? launch_f2_tile<2, 4>(p, s) : launch_f2_tile<2, 2>(p, s);
 }
 
 }  // namespace r2dm

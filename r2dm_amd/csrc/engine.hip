@@ -52,7 +52,8 @@ struct ConvLayer {
     // second packing of the same weights for ALGO_F16X2 (conv_f16x2.hip): the residual blocks' 3x3 convolutions, whose
     // input is GroupNorm-normalised; selected per launch by the handle's precision mode (r2dm_set_conv_pieces)
     bool f2 = false;
-    int f2_cot = 64;  // output channels per tile of that packing: 64 (two accumulators) or 128 (one; conv_f16x2_pick_co_tile)
+    int f2_cot = 64;  // output channels per tile of that packing: 64 or 128 (conv_f16x2_pick_co_tile)
+    int f2_rows = 4;  // ... and its image rows: 4, or 8 (the one-accumulator 64 x 8 tile: its own packing, residual planes at their true scale)
     size_t w_f2 = 0, ws_f2 = 0;  // ws_*: two floats -- [0] max|w| (packer scratch), [1] inverse of the packer's power-of-two weight scale
     // ... and for ALGO_P1F16 (proj_f16x2.hip): the 1x1 projections of the attention block
     bool p1 = false;
@@ -181,7 +182,7 @@ struct r2dm_handle {
         }();
         if (L.algo == ALGO_BF16X3 && H > 0 && conv_f16x2_supported(cin, cout, L.taps, H, W) && (px_batch / 256) * (cout / 64) >= f2_min_tiles) {
             L.f2 = true;
-            L.f2_cot = conv_f16x2_pick_co_tile(cin, cout, H, W, px_batch);
+            L.f2_cot = conv_f16x2_pick_co_tile(cin, cout, H, W, px_batch, &L.f2_rows);
             L.w_f2 = take((size_t)conv_f16x2_packed_floats(cin, cout));
             L.ws_f2 = take(2);
         }
@@ -484,7 +485,7 @@ struct Ctx {
         static const int presplit_min_cout = getenv("R2DM_F2_PRESPLIT_MIN_COUT") ? atoi(getenv("R2DM_F2_PRESPLIT_MIN_COUT")) : 0;  // (0: never)
         const bool f2_launch = L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded);
         float* xs = nullptr;
-        if (f2_launch && L.f2_cot == 64 && presplit_min_cout > 0 && L.cout >= presplit_min_cout && presplit_supported(x, L.cin, H, W))
+        if (f2_launch && L.f2_cot == 64 && L.f2_rows == 4 && presplit_min_cout > 0 && L.cout >= presplit_min_cout && presplit_supported(x, L.cin, H, W))
             xs = (float*)ar->alloc((size_t)presplit_floats(B, L.cin, H, W) * sizeof(float));
         if (!dry()) {
             ConvParams p;
@@ -517,6 +518,7 @@ struct Ctx {
                 p.w = blob(L.w_f2);
                 p.wscale = blob(L.ws_f2) + 1;
                 p.co_tile = L.f2_cot;
+                p.px_rows = L.f2_rows;
                 p.pieces = h->conv_pieces;
             }
             // deep layers (many 64-channel output tiles): the input transform once, by the pre-pass (presplit.hip)
@@ -869,6 +871,16 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
     return 0;
 }
 
+__global__ void raise_range_bound_kernel(int* flag, float bound) { atomicMax(flag + 1, __float_as_int(bound)); }
+
+int r2dm_test_raise_range_bound(r2dm_handle* h, float bound, void* stream) {
+    if (!h || !h->blob) return fail(1, "no weights bound");
+    if (!(bound >= 0.f)) return fail(1, "bound must be non-negative");
+    raise_range_bound_kernel<<<1, 1, 0, (hipStream_t)stream>>>((int*)(h->blob + h->range_flag), bound);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel, void* stream) {
     if (!h || !src) return fail(1, "null argument");
     if (!h->blob) return fail(1, "bind a blob first");
@@ -887,7 +899,7 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
                                  s.conv.cin_pad, st, s.conv.algo, s.conv.src_cin, s.conv.src_off));
         if (s.conv.f2)
             HIP_TRY(launch_pack_conv_f16x2(src, h->blob + s.conv.w_f2, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st,
-                                           h->blob + s.conv.ws_f2, s.conv.f2_cot));
+                                           h->blob + s.conv.ws_f2, s.conv.f2_cot, s.conv.f2_rows));
         if (s.conv.p1)
             HIP_TRY(launch_pack_proj_f16x2(src, h->blob + s.conv.w_p1, s.conv.cout, s.conv.cin, (int*)(h->blob + h->range_flag), st,
                                            h->blob + s.conv.ws_p1));
@@ -1052,12 +1064,12 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces != 3 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
     if (p.algo == ALGO_F32 && g_single_kernel_pieces < 3 && prologue != PRO_AFFINE_SILU && proj_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_P1F16;
     if (p.algo == ALGO_F16X2 || p.algo == ALGO_P1F16) p.pieces = g_single_kernel_pieces;
-    p.co_tile = p.algo == ALGO_F16X2 ? conv_f16x2_pick_co_tile(cin, cout, H, W, (long)B * H * W) : p.algo == ALGO_P1F16 ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
+    p.co_tile = p.algo == ALGO_F16X2 ? conv_f16x2_pick_co_tile(cin, cout, H, W, (long)B * H * W, &p.px_rows) : p.algo == ALGO_P1F16 ? 64 : p.algo == ALGO_BF16X3 ? conv_bf16x3_co_tile(cin, cout, (long)B * H * W) : conv_pick_co_tile(cout, p.taps, (long)B * H * W);
     p.CinPad = p.algo != ALGO_F32 ? cin : conv_cin_pad(cin, p.taps, p.co_tile);
     if (p.algo == ALGO_F16X2) {  // the range flag and the weight scale: behind the packed weights (r2dm_conv_packed_elems reserves 64 floats)
         float* tail = w_packed + conv_f16x2_packed_floats(cin, cout);
         HIP_TRY(hipMemsetAsync(tail, 0, sizeof(int), st));
-        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, (int*)tail, st, tail + 2, p.co_tile));
+        HIP_TRY(launch_pack_conv_f16x2(w, w_packed, cout, cin, (int*)tail, st, tail + 2, p.co_tile, p.px_rows));
         p.wscale = tail + 3;
     } else if (p.algo == ALGO_P1F16) {
         float* tail = w_packed + proj_f16x2_packed_floats(cin, cout);
@@ -1086,7 +1098,7 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     if (const char* e = getenv("R2DM_CONV_PROF_PTR")) p.prof = (unsigned long long*)strtoull(e, nullptr, 0);
     // per-kernel tests / probes of the operand pre-pass (presplit.hip + conv_f16x2's PRO_PRESPLIT stagers): R2DM_F2_PRESPLIT=1
     float* xs = nullptr;
-    if (const char* e = getenv("R2DM_F2_PRESPLIT"); e && atoi(e) && p.algo == ALGO_F16X2 && p.co_tile == 64 && presplit_supported(p.x, cin, H, W)) {
+    if (const char* e = getenv("R2DM_F2_PRESPLIT"); e && atoi(e) && p.algo == ALGO_F16X2 && p.co_tile == 64 && p.px_rows == 4 && presplit_supported(p.x, cin, H, W)) {
         static float* scratch = nullptr;  // (test entry: one growing scratch buffer, never freed)
         static size_t scratch_floats = 0;
         const size_t need = (size_t)presplit_floats(B, cin, H, W);

@@ -67,6 +67,85 @@ def _early_range_check(model, num_steps: int) -> bool:
     return check()
 
 
+_CHECK_EVERY = 32  # steps between two range checks of a sampling loop: one stream synchronisation each, at most so many steps to replay
+
+
+class _Replay:
+    """Recovery from a range-guard trip at ANY step of a ``sample`` loop (missing #2; the reference samples any
+    finite checkpoint, /root/reference/models/diffusion/continuous_time.py:246-257).  The loop keeps ``x`` of the last step whose
+    check passed and the noise it has drawn since; after step 0 of a longer loop, every ``_CHECK_EVERY`` steps and at the end the
+    denoiser's guard is read (EfficientUNet.check_range_or_fall_back); on a trip the denoiser has switched itself to the wide-range
+    operand split (one RuntimeWarning) and the loop goes back to that ``x`` and runs the steps since on the RECORDED noise -- same
+    draws, no exception, at most ``_CHECK_EVERY`` steps lost, once per model.  ``strict_range``: the check raises instead (after
+    step 0 of loops longer than 8 steps, else at the loop's end).  Any other denoiser: nothing is checked or kept."""
+
+    def __init__(self, model, num_steps: int, every: int = _CHECK_EVERY):
+        model = getattr(model, "_orig_mod", model)  # (torch.compile wrapper)
+        check = getattr(model, "check_range_or_fall_back", None)
+        self.check = check if callable(check) else None
+        self.strict = bool(getattr(model, "strict_range", False))
+        self.n, self.every = num_steps, every
+        self.ck_i, self.ck_x, self.noise, self.replays = 0, None, [], 0
+
+    def start(self, x):
+        self.ck_x = x
+
+    def noise_for(self, i: int, draw):
+        """The noise of step i: what was drawn for it before a replay, else ``draw()`` (recorded while a guard is watching)."""
+        k = i - self.ck_i
+        if k < len(self.noise):
+            return self.noise[k]
+        nz = draw()
+        if self.check is not None:
+            self.noise.append(nz)
+        return nz
+
+    def due(self, i: int) -> bool:
+        if self.check is None:
+            return False
+        early = i == 0 and self.n > 8  # a checkpoint the fp16 operand path cannot run at all: found after one step
+        if self.strict:
+            return early  # (its loop-end check is the deferred guard's: raises there)
+        return early or i == self.n - 1 or (i + 1) % self.every == 0
+
+    def after_step(self, i: int, x):
+        """-> (next step, its input): (i + 1, x), or the checkpoint if the guard tripped since it was taken."""
+        if not self.due(i):
+            return i + 1, x
+        if self.check():
+            self.replays += 1
+            self.noise = self.noise[: i + 1 - self.ck_i]
+            return self.ck_i, self.ck_x
+        self.ck_i, self.ck_x, self.noise = i + 1, x, []
+        return i + 1, x
+
+
+def _progress_bar(total: int, desc: str, enabled: bool):
+    try:
+        return tqdm(total=total, desc=desc, leave=False, disable=not enabled)
+    except TypeError:  # (the stand-in above: no bar)
+        return None
+
+
+def _rng_snapshot(rng, dev):
+    """States of whatever ``GaussianDiffusion.randn`` draws from (base.py:71-94 forms), to repeat a loop on the same draws."""
+    if rng is None:
+        return torch.cuda.get_rng_state(dev) if torch.device(dev).type == "cuda" else torch.get_rng_state()
+    if isinstance(rng, torch.Generator):
+        return rng.get_state()
+    return [g.get_state() for g in rng]
+
+
+def _rng_restore(snap, rng, dev):
+    if rng is None:
+        torch.cuda.set_rng_state(snap, dev) if torch.device(dev).type == "cuda" else torch.set_rng_state(snap)
+    elif isinstance(rng, torch.Generator):
+        rng.set_state(snap)
+    else:
+        for g, s in zip(rng, snap):
+            g.set_state(s)
+
+
 def _log(t: torch.Tensor, eps: float = 1e-20) -> torch.Tensor:
     return torch.log(t.clamp(min=eps))
 
@@ -390,18 +469,27 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         if return_all:
             out = [x]
         row, mode_id = self._table_rows(num_steps, batch_size, mode, ddim_eta, dev)
+        rp = _Replay(self.model, num_steps)  # (a range-guard trip at any step: back to the last checked x, on the recorded noise)
+        rp.start(x)
+        bar = _progress_bar(num_steps, "sampling", progress)
         with _range_guard(self.model):
-            for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+            i = 0
+            while i < num_steps:
                 cond_i, coef_i = row(i)
-                noise, drawn = self._randn_like_ahead(x, rng=rng)
+                noise, drawn = rp.noise_for(i, lambda: self._randn_like_ahead(x, rng=rng))
                 prediction = self.model(x, cond_i)
-                if i == 0 and _early_range_check(self.model, num_steps):  # a checkpoint the fp16 operand path cannot run: found
-                    prediction = self.model(x, cond_i)                    # now, not after the loop; repeated on the wide-range split
                 if drawn is not None:
                     torch.cuda.current_stream(x.device).wait_event(drawn)
-                x = self._posterior(x, prediction, noise, coef_i, mode_id)
+                nxt, x = rp.after_step(i, self._posterior(x, prediction, noise, coef_i, mode_id))
                 if return_all:
-                    out.append(x)
+                    del out[nxt + 1:]  # (after a replay: the steps that are run again; else nothing)
+                    if nxt > i:
+                        out.append(x)
+                if bar is not None:
+                    bar.update(nxt - i)
+                i = nxt
+        if bar is not None:
+            bar.close()
         return torch.stack(out) if return_all else x
 
     # -- forward process pieces used by RePaint (continuous_time.py:169-190) ----------------
@@ -442,7 +530,17 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
     @torch.inference_mode()
     def repaint(self, known, mask, num_steps: int, num_resample_steps: int = 1, jump_length: int = 1,
                 progress: bool = True, rng=None, return_all: bool = False):
-        """RePaint inpainting on top of the same p_step (continuous_time.py:260-317)."""
+        """RePaint inpainting on top of the same p_step (continuous_time.py:260-317).  A range-guard trip that only shows after the
+        first step (``_early_check``) ends the loop with the denoiser switched to the wide-range split: the call is then repeated
+        once, from the generator states it started with -- same draws, no exception (the reference runs any finite checkpoint)."""
+        snap = _rng_snapshot(rng, self.device)
+        try:
+            return self._repaint(known, mask, num_steps, num_resample_steps, jump_length, progress, rng, return_all)
+        except _lib.R2DMRangeFallback:
+            _rng_restore(snap, rng, self.device)
+            return self._repaint(known, mask, num_steps, num_resample_steps, jump_length, progress, rng, return_all)
+
+    def _repaint(self, known, mask, num_steps, num_resample_steps, jump_length, progress, rng, return_all):
         assert num_resample_steps > 0
         assert jump_length > 0
         B = known.shape[0]
@@ -544,15 +642,24 @@ class DiscreteTimeGaussianDiffusion(GaussianDiffusion):
         coef, mode_id = self._coefficients(order, mode, 0.0)
         coef = coef[:, None, :].expand(num_steps, batch_size, _NCOEF).contiguous().to(dev)
         cond = order[:, None].expand(num_steps, batch_size).contiguous().to(dev)
+        rp = _Replay(self.model, num_steps)  # (as ContinuousTimeGaussianDiffusion.sample)
+        rp.start(x)
+        bar = _progress_bar(num_steps, "sampling", progress)
         with _range_guard(self.model):
-            for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-                noise, drawn = self._randn_like_ahead(x, rng=rng) if mode_id != _M_DT_DDIM else (None, None)
+            i = 0
+            while i < num_steps:
+                noise, drawn = rp.noise_for(i, lambda: self._randn_like_ahead(x, rng=rng)) if mode_id != _M_DT_DDIM else (None, None)
                 prediction = self.model(x, cond[i])
-                if i == 0 and _early_range_check(self.model, num_steps):
-                    prediction = self.model(x, cond[i])  # (repeated on the wide-range operand split)
                 if drawn is not None:
                     torch.cuda.current_stream(x.device).wait_event(drawn)
-                x = self._posterior(x, prediction, noise, coef[i], mode_id)
+                nxt, x = rp.after_step(i, self._posterior(x, prediction, noise, coef[i], mode_id))
                 if return_all:
-                    out.append(x)
+                    del out[nxt + 1:]
+                    if nxt > i:
+                        out.append(x)
+                if bar is not None:
+                    bar.update(nxt - i)
+                i = nxt
+        if bar is not None:
+            bar.close()
         return torch.stack(out) if return_all else x

@@ -336,8 +336,13 @@ class EfficientUNet(nn.Module):
             raise
         else:
             self._defer_range_check = outer
-            if not outer:
-                self.check_range()
+            # a trip that is only seen here used to raise with strict_range off and leave the model on the fp16 path,
+            # so every later call failed the same way.  Now the model switches (check_range_or_fall_back) and says so: the loops that
+            # can replay themselves (sample: diffusion._Replay; repaint: from the saved generator states) never get here tripped.
+            if not outer and self.check_range_or_fall_back():
+                raise _lib.R2DMRangeFallback(
+                    "the fp16 operand range guard tripped inside this loop: its results are not valid.  The model now runs the wide-range "
+                    "operand split 'fp32-bf16x3' -- repeat the call (same generators re-seeded) to get them")
 
     # -- measurement aid ---------------------------------------------------------------------------
     def profile_convs(self, on: bool):

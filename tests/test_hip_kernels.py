@@ -87,8 +87,9 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
     fp32-class: max error < 1e-5 on O(1) outputs.  Two yardsticks measured in the same test: the fp32-MFMA kernel as ONE fmaf chain
     (pieces = 5: what fp32 arithmetic is) and as the library runs it (pieces = 4: two-level accumulation above 128 channels).  Bars:
     every split kernel's rms error <= the plain chain's, at every depth; the two-accumulator tile <= 1.1x the two-level kernel's; the
-    one-accumulator tile (three truncating accumulator updates per tap instead of one) <= 1.0x of it up to Cin = 128 and <= 1.3x at
-    Cin = 256 -- the depths conv_f16x2_pick_co_tile uses it at (measured 0.66-0.70x / 1.2x; 1.7x at Cin = 512: not dispatched there)."""
+    one-accumulator tiles (three truncating accumulator updates per tap instead of one; 128 channels x 4 rows, and since round 5
+    64 channels x 8 rows: bit-identical to each other) <= 1.0x of it up to Cin = 128 and <= 1.3x at
+    Cin = 256 -- the depths conv_f16x2_pick_co_tile uses them at (measured 0.66-0.70x / 1.2x; 1.7x at Cin = 512: not dispatched there)."""
     import torch.nn.functional as F
 
     B = 3
@@ -102,7 +103,8 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
         xa = F.silu(xa)
     ref = (res.double() + O.conv_ring(xa, wt.double(), b.double())) * 0.70710678
     out = {}
-    variants = [("f16x2/64", 2, "64"), ("bf16x3", 3, None), ("f32 mfma", 4, None), ("f32 chain", 5, None)] + ([("f16x2/128", 2, "128")] if cout % 128 == 0 else [])
+    variants = ([("f16x2/64", 2, "64"), ("bf16x3", 3, None), ("f32 mfma", 4, None), ("f32 chain", 5, None)] + ([("f16x2/128", 2, "128")] if cout % 128 == 0 else [])
+                + ([("f16x2/64x8", 2, "64x8")] if h % 8 == 0 else []))  # (round 5: the one-accumulator tile of 64 channels x 8 rows)
     saved = os.environ.get("R2DM_F2_CO_TILE")
     for name, pieces, tile in variants:
         H.set_conv_pieces(pieces)
@@ -121,7 +123,7 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
     assert not torch.equal(out["f16x2/64"], out["bf16x3"]) and not torch.equal(out["f16x2/64"], out["f32 mfma"])  # the mode switches took effect
     assert all(v[0] < 1e-5 for k, v in e.items() if k != "f32 chain")  # (the plain chain is a yardstick, not a product path: 1.0e-5 at K = 4608)
     assert e["f16x2/64"][1] < (0.75 if cin <= 128 else 1.5) * e["bf16x3"][1]
-    for k in ("f16x2/64", "f16x2/128"):
+    for k in ("f16x2/64", "f16x2/128", "f16x2/64x8"):
         if k in e:
             assert e[k][1] <= e["f32 chain"][1], (k, e)  # at or below an fp32 fmaf chain, at every depth
             bar = 1.0 if cin <= 128 else 1.1 if k == "f16x2/64" else 1.3 if cin <= 256 else 2.0
@@ -130,6 +132,10 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
         assert not torch.equal(out["f32 mfma"], out["f32 chain"]) and e["f32 mfma"][1] < e["f32 chain"][1]  # (the hook took effect; two levels pay)
     if "f16x2/128" in e:
         assert not torch.equal(out["f16x2/64"], out["f16x2/128"])  # (the 128-channel tile really ran)
+    if "f16x2/64x8" in e:
+        assert not torch.equal(out["f16x2/64"], out["f16x2/64x8"])  # (the eight-row tile really ran)
+        if "f16x2/128" in e:  # both one-accumulator tiles do the same arithmetic per output element, in the same order
+            assert torch.equal(out["f16x2/128"], out["f16x2/64x8"])
 
 
 @pytest.mark.parametrize("pro", [0, 1, 2])

@@ -274,3 +274,52 @@ def test_weight_flag_survives_blob_adoption():
     b.model.adopt_packed_weights(blob)
     with pytest.raises(R2DMError, match="not finite"):
         b.model(x, c)
+
+
+def test_late_range_guard_trip_is_replayed_from_the_last_checked_step():
+    """VERDICT round 4, missing #2: a guard that trips only late in a loop (low t) used to raise after the last step and lose the call.
+    A 40-step seeded loop whose guard is raised behind denoiser call 35 (the C ABI's test hook writes the bound a saturating operand
+    would have left): the checks after steps 0 and 31 pass, the one at the end trips -- ONE RuntimeWarning, the model switches to
+    'fp32-bf16x3', steps 32..39 run again on the recorded noise (8 extra denoiser calls, no new draws), no exception; the sample
+    agrees with a model that ran 'fp32-bf16x3' from the start to the parity class of the two splits (steps 0..31 ran on the fp16
+    split), and a second call runs clean on the wide split, bit-identical to that model."""
+    import warnings
+
+    import r2dm_amd
+    from r2dm_amd import _lib
+
+    ck = synthetic_ckpt()
+    wide, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2, precision="fp32-bf16x3")
+    s_wide = wide.sample(batch_size=2, num_steps=40, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV))
+    b, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    calls = []
+    fwd = b.model.forward
+
+    def forward(*a, **k):
+        y = fwd(*a, **k)
+        calls.append(1)
+        if len(calls) == 35:
+            _lib.check(_lib.lib().r2dm_test_raise_range_bound(b.model._engine.h, 1.0e5, _lib.stream_ptr(y.device)))
+        return y
+
+    b.model.forward = forward
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s = b.sample(batch_size=2, num_steps=40, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV))
+    assert sum(issubclass(i.category, RuntimeWarning) and "fp32-bf16x3" in str(i.message) for i in w) == 1
+    assert len(calls) == 48 and b.model.precision == "fp32-bf16x3" and b.model.range_fallbacks == 1
+    assert torch.isfinite(s).all() and max_abs(s.cpu(), s_wide.cpu()) < 2e-5
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s2 = b.sample(batch_size=2, num_steps=40, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV))
+    assert not w and torch.equal(s2, s_wide)
+    # return_all keeps one entry per step through a replay
+    c, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2)
+    n = []
+    fwd_c = c.model.forward
+    c.model.forward = lambda *a, **k: (n.append(1), fwd_c(*a, **k), len(n) == 3 and _lib.check(_lib.lib().r2dm_test_raise_range_bound(c.model._engine.h, 1.0e5, _lib.stream_ptr(DEV))))[1]
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        allx = c.sample(batch_size=2, num_steps=6, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV), return_all=True)
+    assert allx.shape[0] == 7 and len(n) == 12
+    assert torch.equal(allx[-1], wide.sample(batch_size=2, num_steps=6, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV)))

@@ -80,7 +80,8 @@ struct Geo {
     static constexpr int RES0 = PATCH0 + (ONEACC ? 0 : 4 * 1024);  // four waves x RESQ x 4 KiB (one-accumulator tiles: no separate patches -- the turn of the
                                                                 // immediate quarters goes through the wave's first waiting slot, which is empty at a tile's end)
     static constexpr int ADTAB0 = RES0 + 4 * RESQ * 4096;
-    static constexpr int LDS_TOTAL = ADTAB0 + ADTAB_BYTES;      // 157952 (2, 2) | 162048 (4, 2) | 159488 (2, 4) | 108032 (2, 1)
+    static constexpr int BIAS0 = ADTAB0 + ADTAB_BYTES;          // one-accumulator tiles: the biases of the block's current tiles, two slots of COT floats (by tile parity)
+    static constexpr int LDS_TOTAL = BIAS0 + (ONEACC ? 2 * COT * 4 : 0);  // 157952 (2, 2) | 163072 (4, 2) | 160000 (2, 4)
     static constexpr int UNITS_X = NG * XR * 18;                // staging units of a chunk: 8 channels x 4 pixels of one row (16 interior quads + 2 halo columns per row)
     static constexpr int NU = (UNITS_X + 255) / 256;            // ... per staging thread (1 | 2)
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS");
@@ -108,8 +109,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     // (the tile's own geometry shadows x3's constants of the same names)
     constexpr int MR = MRK, NR = NRK, TH = GEO::TH, XR = GEO::XR, XPL = GEO::XPL, XBYTES = GEO::XBYTES, NQ = GEO::NQ, NU = GEO::NU;
     constexpr int COT = GEO::COT, WSTAGE = GEO::WSTAGE, RING = GEO::RING, WB0 = GEO::WB0, PATCH0 = GEO::PATCH0, RESQ = GEO::RESQ,
-                  RES0 = GEO::RES0, ADTAB0 = GEO::ADTAB0;
+                  RES0 = GEO::RES0, ADTAB0 = GEO::ADTAB0, BIAS0 = GEO::BIAS0;
     constexpr bool ONEACC = GEO::ONEACC;
+    // Round 5, the tile end of the one-accumulator tiles (-DF2_EPI_V1: round 4's, for A/B): biases wait in an LDS table the stagers fill
+    // three chunks ahead (requested at the tile's end they cost its first quarter ~1.9 k cycles), the residual of the first two quarters is
+    // prefetched by LDS-DMA during the tile's last chunk (no registers: requested at the tile's end the first quarters waited for HBM, 10 k
+    // cycles per tile of the eight-row tile), and all eight quarters are finished at the tile's end (no row block waits in LDS: the
+    // multipliers bound a chunk of these tiles, a deferred quarter costs what it takes wherever it runs).
+#ifdef F2_EPI_V1
+    constexpr bool EPI2 = false;
+#else
+    constexpr bool EPI2 = ONEACC;
+#endif
     // the cross products go to a second accumulator (scaled l planes) or, in the one-accumulator tiles, to the same one (l planes at their true scale)
     constexpr bool ACC2 = NPLK == 2 && !ONEACC;
     constexpr bool LSCALED = !ONEACC;
@@ -467,6 +478,20 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("" : "+v"(tab_v));
             if (tab_lane) *reinterpret_cast<f32x4*>(smem + ADTAB0 + t4 * 16) = tab_v;
         };
+        // ---- the tile's biases (EPI2): fetched while its chunk 1 is staged (three or more chunks before the multipliers want them), one float
+        // per thread, into the slot of the tile's parity -- read last at the end of the tile two back
+        float bias_v = 0.f;
+        auto bias_fetch = [&]() __attribute__((always_inline)) {  // one VMEM operation, counted by hand like the others
+            int cot, b, th, tw;
+            decode(t_item < nIt ? t_item : nIt - 1, cot, b, th, tw);
+            const unsigned char* src = sbase(p.bias + cot * COT);
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(bias_v) : "v"(t4 < COT ? (unsigned)t4 * 4u : 0u), "s"(src) : "memory");
+        };
+        auto bias_store = [&](auto NEWER) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NEWER)::value) : "memory");
+            asm volatile("" : "+v"(bias_v));
+            if (t4 < COT) *reinterpret_cast<float*>(smem + BIAS0 + ((t_item & 1) * COT + t4) * 4) = bias_v;
+        };
         auto table_read = [&](int u, bool ok, bool edge) __attribute__((always_inline)) {  // unit u's 8 channels of chunk x_c
             if (PRO == PRO_NONE) return;
             const int j0 = (x_c * CK + s_g[u] * 8) >> 1;
@@ -620,7 +645,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                               NEWER3 = RING == 4 ? 2 * PPW + NLc : PPW + NLc;
                 unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
                 const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
+                const bool bias_now = EPI2 && x_c == 1;  // (nchunks >= 4: never the iteration of the table fetch or store)
                 if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
+                if (bias_now) bias_fetch();          // (likewise)
                 dma_stage(3 * q, ic<RING - 1>{});    // D0
                 if (q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLp + PPW) : "memory");  // (only chunk 2 and D0 are younger than chunk 1)
                 use_set(cur, NCUR, ic<4 * PPW + NLp>{});  // raw(q+1): requested two iterations ago (the previous iteration's queue and D0 are younger)
@@ -643,6 +670,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     table_store(ic<5 * PPW + NLp>{});  // of the previous iteration) goes to LDS
                     ++t_item;
                 }
+                if (bias_now) bias_store(ic<2 * PPW>{});  // (fetched at this iteration's start: D0 and D1 are younger; published by #3)
                 x_c = last_of_tile ? 0 : x_c + 1;
                 dma_stage(3 * q, ic<RING + 1>{});    // D2
                 load_next(cur, NCUR);                // pixels of chunk q+3
@@ -866,6 +894,21 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         for (int k8 = 0; k8 < 4; ++k8) rv[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
     };
     auto res_request = [&](auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) { res_request_to(rv_e, QD, b, th, tw, cot, ln); };
+    // quarter QD's residual -> the wave's waiting slot QD (0 | 1) by LDS-DMA: four pieces of 1 KiB (one 8-channel block each)
+    auto res_dma = [&](auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) {
+        constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
+        static_assert(qd < RESQ, "waiting slots");
+        const int s = wave * NR + n;
+        const unsigned voff = (unsigned)((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) * 4u;
+        const unsigned dst = lds0 + RES0 + (unsigned)((wave * RESQ + qd) * 4096);
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            const unsigned long long sv = (unsigned long long)(p.res + b * p.res_bs + (long)(cot * COT + m * 32 + k8 * 8) * HW);
+            const unsigned char* src = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
+                                                              (unsigned)__builtin_amdgcn_readfirstlane((int)sv));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(dst + (unsigned)k8 * 1024u) : "memory", "m0");
+        }
+    };
     // the turn: this wave's accumulator quarter (m, n) -> dst[8-channel block][8 channels][32 pixels]
     auto turn_write = [&](auto QD, float* dst, int ln) __attribute__((always_inline)) {
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
@@ -951,15 +994,107 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 }
                 // (the eight-row tile cannot hold 16 residual registers through a chunk -- as loads here they were spilled one by one behind
                 // vmcnt(0): its first quarter's residual is requested at the tile's end, in front of the biases that quarter waits for anyway)
-                if constexpr (NR != 4) res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
+                if constexpr (EPI2) {
+                    // the residual of quarters 0 and 1 by LDS-DMA into the wave's two waiting slots (4 KiB each: block k8 at 1 KiB k8, lane L's
+                    // four pixels at 16 L -- the turned layout, read back with one ds_read_b128 per block); no register is written
+                    if (p.res) {
+                        res_dma(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
+                        res_dma(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
+                    }
+                } else if constexpr (NR != 4) res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
             }
         }
         tap(q, ic<0>{}, PAR); tap(q, ic<1>{}, PAR); tap(q, ic<2>{}, PAR);
         tap(q, ic<3>{}, PAR); tap(q, ic<4>{}, PAR); tap(q, ic<5>{}, PAR);
         tap(q, ic<6>{}, PAR); tap(q, ic<7>{}, PAR); tap(q, ic<8>{}, PAR);
         ++e_c;
-        if constexpr (ONEACC) {
-            // ---- 128-channel tile and eight-row tile: ONE accumulator per MFMA tile, eight quarters (m, n) per wave, numbered qd = m NR + n, in pairs
+        if constexpr (EPI2) {
+            // ---- one-accumulator tiles, round 5: eight quarters (m, n) per wave, numbered qd = m NR + n, in pairs (2 M, 2 M + 1) that share a
+            // statistics slot, ALL finished at the tile's end.  Biases: LDS table (stagers).  Residual: quarters 0 and 1 from the wave's two
+            // waiting slots (LDS-DMA, requested a chunk ago), quarters 2 .. 7 through four register buffers -- 2, 3 requested here (they have
+            // quarters 0 and 1, ~2 k cycles, to arrive), each buffer refilled for the quarter four further on as soon as it is free.
+            if constexpr (decltype(PAR)::value == 1) {
+                if (e_c == nchunks) {
+                    e_c = 0;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
+                    stamp(7);
+                    const int ln = fresh_lane();
+                    const int l31e = ln & 31, hie = ln >> 5;
+                    f32x4 rvA[4] = {}, rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
+                    // the DMA of this tile's last chunk has had the chunk to land; hipcc does not see it: an explicit wait, in front of every
+                    // memory operation of the tile's end (nothing else of this wave is in flight: the wait is for the DMA alone)
+                    if (p.res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
+                    // (eight-row tile: the fourth buffer is requested behind quarter 0, whose accumulator registers it takes -- requested here it
+                    // was spilled behind vmcnt(0))
+                    if constexpr (NR != 4) res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                    const float* btab = reinterpret_cast<const float*>(smem + BIAS0) + (e_item & 1) * COT + (ln >> 3);
+                    auto bias_load = [&](auto M) __attribute__((always_inline)) {
+                        constexpr int m = decltype(M)::value;
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = btab[m * 32 + k8 * 8];
+                    };
+                    bias_load(ic<0>{});
+                    if (p.res) {
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {
+                            rvA[k8] = *reinterpret_cast<const f32x4*>(dump + k8 * 256 + ln * 4);
+                            rv1[k8] = *reinterpret_cast<const f32x4*>(dump + 1024 + k8 * 256 + ln * 4);
+                        }
+                    }
+                    auto do_q = [&](auto QD, f32x4 (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+                        constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
+                        f32x4 t[4];
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {  // (the patch is the wave's first waiting slot: its residual is in registers by now -- LDS operations of a wave are in order)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) patch[(j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
+                            t[k8] = *reinterpret_cast<const f32x4*>(patch + (ln >> 3) * 32 + (ln & 7) * 4);
+                        }
+                        quarter(QD, t, rv, e_b, e_th, e_tw, e_cot, ln, ps, pq);
+                    };
+                    float ps0[4], pq0[4], ps1[4], pq1[4];
+                    stamp(20);
+                    do_q(ic<0>{}, rvA, ps0, pq0);
+                    stamp(21);
+                    if constexpr (NR == 4) res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                    res_request_to(rvA, ic<4>{}, e_b, e_th, e_tw, e_cot, ln);
+                    do_q(ic<1>{}, rv1, ps1, pq1);
+                    stamp(22);
+                    res_request_to(rv1, ic<5>{}, e_b, e_th, e_tw, e_cot, ln);
+                    half_stats(ic<0>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    stamp(23);
+                    bias_load(ic<1>{});
+                    do_q(ic<2>{}, rv2, ps0, pq0);
+                    stamp(24);
+                    res_request_to(rv2, ic<6>{}, e_b, e_th, e_tw, e_cot, ln);
+                    do_q(ic<3>{}, rv3, ps1, pq1);
+                    res_request_to(rv3, ic<7>{}, e_b, e_th, e_tw, e_cot, ln);
+                    half_stats(ic<1>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    if constexpr (MR == 4) bias_load(ic<2>{});
+                    do_q(ic<4>{}, rvA, ps0, pq0);
+                    do_q(ic<5>{}, rv1, ps1, pq1);
+                    half_stats(ic<2>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    if constexpr (MR == 4) bias_load(ic<3>{});
+                    do_q(ic<6>{}, rv2, ps0, pq0);
+                    do_q(ic<7>{}, rv3, ps1, pq1);
+                    half_stats(ic<3>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                    range_flush(ln);
+                    stamp(8);
+                    // (the accumulators restart from C = 0 in the next tile's first products: end the old values' lives)
+                    if constexpr (MR == 4) {
+                        asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
+                        asm volatile("" : "=v"(acc[2][0]), "=v"(acc[2][1]), "=v"(acc[3][0]), "=v"(acc[3][1]));
+                    } else {
+                        asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[0][2]), "=v"(acc[0][3]));
+                        asm volatile("" : "=v"(acc[1][0]), "=v"(acc[1][1]), "=v"(acc[1][2]), "=v"(acc[1][3]));
+                    }
+                    if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
+                    frag_first(lds_w0);  // (stage 3 (q + 1): ring slot 0)
+                }
+            }
+        } else if constexpr (ONEACC) {
+            // ---- 128-channel tile and eight-row tile (round 4's tile end, -DF2_EPI_V1): ONE accumulator per MFMA tile, eight quarters (m, n) per wave, numbered qd = m NR + n, in pairs
             // (2 M, 2 M + 1) that share a statistics slot (128 channels: row block M, both 32-pixel segments of the wave's row; eight rows: row
             // block M / 2, the wave's row M % 2).  Six are finished at the tile's end, the
             // last row block's two (6, 7) wait, turned, in 32 KiB of LDS and are finished behind the next tile's first two chunks (the
@@ -1257,7 +1392,9 @@ int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_b
     static const bool tall_on = !getenv("R2DM_F2_TALL") || atoi(getenv("R2DM_F2_TALL")) != 0;
     const long px_tiles = pixels_times_batch / (4 * f2::TW);
     if (wide_ok && Cin <= max_cin && px_tiles * (Cout / 128) >= f2_cu_count()) return 128;
-    if (tall_ok && tall_on && px_rows && Cin <= max_cin && (px_tiles / 2) * (Cout / 64) >= f2_cu_count()) rows = 8;
+    // (the eight-row tile pays where a block has enough chunks to amortise its longer tile end: measured per launch at batch 8, profiles/r05_tall_tile.txt --
+    // level-1 64 -> 64 -5 %, 128 -> 64 -6 %, 256 -> 64 @ 32 x 512 -4 %; 64 -> 64 @ 32 x 512, two four-chunk tiles per block, +3 %: left on the 64 x 4 tile)
+    if (tall_ok && tall_on && px_rows && Cin <= max_cin && (px_tiles / 2) * (Cout / 64) * (long)(Cin / f2::CK) >= 16L * f2_cu_count()) rows = 8;
     return 64;
 }
 

@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 mkdir -p build
 pids=()
 for f in conv_mfma conv_bf16x3 conv_f16x2 proj_f16x2 presplit conv_direct norm resample attention embed posterior engine; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || [ conv_bf16x3.h -nt build/$f.o ] || [ f16x2.h -nt build/$f.o ] || [ wave_ops.h -nt build/$f.o ] || [ ../../include/r2dm_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || [ conv_bf16x3.h -nt build/$f.o ] || [ f16x2.h -nt build/$f.o ] || [ wave_ops.h -nt build/$f.o ] || [ gn_math.h -nt build/$f.o ] || [ ../../include/r2dm_hip.h -nt build/$f.o ]; then
     extra=""; case $f in conv_bf16x3*|conv_f16x2|proj_f16x2|presplit) extra="-fno-slp-vectorize";; esac  # packed f32 VALU next to MFMAs is an anti-lever
     hipcc $FLAGS $extra -c $f.hip -o build/$f.o &
     pids+=($!)

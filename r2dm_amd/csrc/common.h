@@ -37,7 +37,7 @@ __device__ __forceinline__ float silu_f(float v) {
 
 // XCD-aware bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): logical ids that
 // are neighbours (share input halo / weights) land on the same XCD's L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+__host__ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -94,6 +94,18 @@ struct ConvParams {
     // walk the launch's tiles in descending order (conv_f16x2.hip): consecutive layers then alternate direction, so a layer starts on the
     // part of its input that its producer wrote LAST -- the part most likely still in the 256 MB Infinity Cache (level-1 tensors are 134 MB)
     int reverse = 0;
+    // GroupNorm folded into its CONSUMER (conv_f16x2.hip, round 5): instead of `aff` the launch gets the producers' statistics slots
+    // and the norm's parameters; every block's staging waves reduce the slots of the block's sample in gn_finalize_kernel's order
+    // (norm.hip: bit-identical (a, d)) while the first pixels are on their way -- one launch less per GroupNorm.  Only where
+    // conv_f16x2_fold_supported says so; `aff` must be nullptr then.
+    const double* gn_partial = nullptr;  // [B][8][gn_stride][2] fp64 (sum, sum of squares); slots [0, gn_slots) are read
+    int gn_slots = 0, gn_stride = 0, gn_cpg = 0;
+    float gn_eps = 0.f;
+    const float* gn_gamma = nullptr;     // [Cin] / nullptr
+    const float* gn_beta = nullptr;
+    const float* gn_ada = nullptr;       // [B][gn_ada_stride] rows = [scale(Cin) | shift(Cin)] (AdaGN) / nullptr
+    long gn_ada_stride = 0;
+    int* gn_range = nullptr;             // the engine's range flag (the bound gn_finalize would have recorded) / nullptr
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
 int conv_pick_algo(int Cin, int Cout, int taps);  // env R2DM_CONV_ALGO=f32 forces ALGO_F32 everywhere
@@ -125,6 +137,9 @@ hipError_t launch_pack_conv_f16x2(const float* w_oihw, float* dst, int Cout, int
                                   int px_rows = 4);
 hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream_t s);  // max_bits <- float bits of max|w| (zeroed first)
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s);
+// can this launch (shape, tile, batch: everything but the gn_* fields) take its GroupNorm folded -- 8 groups of 8 .. 64 channels, at
+// most 4 x 256 statistics slots per group to read, every block's tiles inside ONE sample
+bool conv_f16x2_fold_supported(const ConvParams& p, int groups, int slots);
 // the operand pre-pass of conv_f16x2 (presplit.hip): xs <- [b][chunk][plane][group][H + 2][W][8 ch] fp16 of silu(x a + d) (prologue as in
 // ConvParams); a convolution with prologue = PRO_PRESPLIT and x.p0 = xs, x.bs0 = presplit_floats(1, Cin, H, W) consumes it
 long presplit_floats(int B, int Cin, int H, int W);

@@ -45,6 +45,7 @@
 #include "conv_bf16x3.h"
 #include "conv_epilogue.h"
 #include "f16x2.h"
+#include "gn_math.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -465,6 +466,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         int x_c = 0;       // chunk (within its tile) that is transformed next
         const f32x4* adtab = reinterpret_cast<const f32x4*>(smem + ADTAB0);
         const bool tab_lane = PRO != PRO_NONE && t4 * 2 < p.Cin;
+        // GroupNorm folded into this launch (ConvParams::gn_partial): the table of the block's ONE sample is computed in the prologue, from
+        // the producers' statistics slots, and never refreshed
+        const bool fold = PRO != PRO_NONE && p.gn_partial != nullptr;
         auto table_fetch = [&](int it) __attribute__((always_inline)) {  // one VMEM operation (asm: counted by hand like the others)
             if (PRO == PRO_NONE) return;
             int cot, b, th, tw;
@@ -590,8 +594,143 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             stamp(30);
             set_load_item(0);
             set_dma_item(0);
-            load_next(set0, N0C);
-            if (PRO != PRO_NONE) {
+            int fold_bits = 0;  // this thread's share of the range bound gn_finalize would have recorded
+            if (PRO != PRO_NONE && fold) {
+                // ---- the GroupNorm of this launch's input, folded in (round 5).  gn_finalize_kernel's reduction, per group g: thread t adds slots
+                // t, t + 256, ... in ascending order, wave_sum_f64, the four waves as (w0 + w1) + (w2 + w3) -- the same slots, order and
+                // arithmetic (gn_math.h), hence the same bits.  All 8 groups at once: <= 4 slots per thread and group (host-checked), two per round in
+                // flight; the pixels of chunk 0 are requested behind the first round and land while it is reduced.
+                using d2 = __attribute__((ext_vector_type(2))) double;
+                int cot0, b0, th0, tw0;
+                decode(0, cot0, b0, th0, tw0);
+                const int cpg = p.gn_cpg, Cn = p.Cin;
+                // the norm's per-channel parameters (w, sh) of the channels this thread will need, requested FIRST (they do not depend on the
+                // statistics: fetched behind them they were a second serial round trip): two table channels, eight per staging unit of chunk 0
+                float wq[2] = {1.f, 1.f}, hq[2] = {0.f, 0.f};       // table channels 2 t4, 2 t4 + 1
+                f32x4 wu[decltype(N0C)::value][2], hu[decltype(N0C)::value][2];
+                {
+                    const bool ada = p.gn_ada != nullptr;
+                    const unsigned char* wb = sbase(ada ? p.gn_ada + b0 * p.gn_ada_stride : p.gn_gamma);
+                    const unsigned char* hb = sbase(ada ? p.gn_ada + b0 * p.gn_ada_stride + Cn : p.gn_beta);
+                    const bool have_w = ada || p.gn_gamma != nullptr, have_h = ada || p.gn_beta != nullptr;
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    f32x2 w2 = {1.f, 1.f}, h2 = {0.f, 0.f};
+                    if (have_w) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w2) : "v"(tab_lane ? (unsigned)t4 * 8u : 0u), "s"(wb) : "memory");
+                    if (have_h) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(h2) : "v"(tab_lane ? (unsigned)t4 * 8u : 0u), "s"(hb) : "memory");
+#pragma unroll
+                    for (int u = 0; u < decltype(N0C)::value; ++u)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            wu[u][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            hu[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (have_w) gload(wu[u][i], wb, (unsigned)(s_g[u] * 8 + 4 * i) * 4u);
+                            if (have_h) gload(hu[u][i], hb, (unsigned)(s_g[u] * 8 + 4 * i) * 4u);
+                        }
+                    // (the waits for the statistics below cover these: they are older)
+                    asm volatile("" : "+v"(w2), "+v"(h2));
+                    wq[0] = w2[0]; wq[1] = w2[1]; hq[0] = h2[0]; hq[1] = h2[1];
+                }
+                const bool is_ada = p.gn_ada != nullptr;  // AdaGN: w = 1 + scale (ops.py:190-200); added below, after the loads have landed
+                auto wfix = [&](float w) __attribute__((always_inline)) { return is_ada ? 1.0f + w : w; };
+                const unsigned char* pb = sbase(p.gn_partial + (size_t)b0 * 8 * p.gn_stride * 2);
+                const int npg = (p.gn_slots + 255) >> 8;
+                double gs[8], gq[8], ge[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) gs[g] = gq[g] = ge[g] = 0.0;
+                for (int r0 = 0; r0 < npg; r0 += 2) {
+                    d2 pv[8][2];
+                    bool live[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int sl = t4 + 256 * (r0 + i);
+                        live[i] = sl < p.gn_slots;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g)
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pv[g][i]) : "v"((unsigned)(g * p.gn_stride + (live[i] ? sl : 0)) * 16u), "s"(pb) : "memory");
+                    }
+                    if (r0 == 0) {
+                        load_next(set0, N0C);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL0) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            asm volatile("" : "+v"(pv[g][i]));
+                            const d2 v = live[i] ? pv[g][i] : d2{0.0, 0.0};
+                            gs[g] += v[0];
+                            gq[g] += v[1];
+                            ge[g] = v[1] > ge[g] ? v[1] : ge[g];
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < decltype(N0C)::value; ++u)
+                    asm volatile("" : "+v"(wu[u][0]), "+v"(wu[u][1]), "+v"(hu[u][0]), "+v"(hu[u][1]));
+                // all eight groups' wave totals with two reduce-scatters (lane L: group (L >> 3) & 7), the maxima one by one
+                double* scr = reinterpret_cast<double*>(smem + RES0);  // [group][wave][sum, squares, max |x| bound] (the waiting slots are idle until the first tile's end)
+                {
+                    const double ta = wave_sum8_scatter(gs, lane), tq = wave_sum8_scatter(gq, lane);
+                    if ((lane & 7) == 0) {
+                        const int g = (lane >> 3) & 7;
+                        scr[(g * 4 + wave) * 3 + 0] = ta;
+                        scr[(g * 4 + wave) * 3 + 1] = tq;
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const float gm = wave_max_f32((float)sqrt(ge[g]) * 1.000001f);
+                        if (lane == 0) scr[(g * 4 + wave) * 3 + 2] = (double)gm;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // P0 (the multipliers pass it too): the waves' totals are published
+                asm volatile("" ::: "memory");
+                const double n_el = (double)cpg * (double)HW;
+                // one group per lane (0 .. 7 of every wave: two fp64 divisions and a square root, once), handed to the lanes that need it through
+                // a private LDS row (LDS operations of a wave are in order: no barrier)
+                float* mrow = reinterpret_cast<float*>(scr + 104) + wave * 32;  // [group][mean, rstd, gmax, well conditioned]
+                if (lane < 8) {
+                    const double* r = scr + lane * 12;
+                    const GnMoments mo = gn_moments((r[0] + r[3]) + (r[6] + r[9]), (r[1] + r[4]) + (r[7] + r[10]), n_el, p.gn_eps);
+                    const float gmax = fmaxf(fmaxf((float)r[2], (float)r[5]), fmaxf((float)r[8], (float)r[11]));
+                    *reinterpret_cast<f32x4*>(mrow + lane * 4) = f32x4{mo.mean, mo.rstd, gmax, mo.well_conditioned ? 1.f : 0.f};
+                }
+                const int csh = __builtin_ctz((unsigned)cpg);  // (cpg is 8, 16, 32 or 64: host-checked)
+                struct GroupOf { GnMoments mo; float gmax; };
+                auto group_of = [&](int c) __attribute__((always_inline)) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(mrow + (c >> csh) * 4);
+                    GroupOf o;
+                    o.mo.mean = v[0]; o.mo.rstd = v[1]; o.mo.well_conditioned = v[3] != 0.f;
+                    o.gmax = v[2];
+                    return o;
+                };
+                if (tab_lane) {  // this thread's two table entries (published by P)
+                    const GroupOf o = group_of(2 * t4);
+                    wq[0] = wfix(wq[0]);
+                    wq[1] = wfix(wq[1]);
+                    const float2 e0 = gn_affine(o.mo, wq[0], hq[0]), e1 = gn_affine(o.mo, wq[1], hq[1]);
+                    *reinterpret_cast<f32x4*>(smem + ADTAB0 + t4 * 16) = f32x4{e0.x, e0.y, e1.x, e1.y};
+                    const int i0 = __float_as_int(gn_bound(o.mo, e0, wq[0], hq[0], o.gmax, n_el)), i1 = __float_as_int(gn_bound(o.mo, e1, wq[1], hq[1], o.gmax, n_el));
+                    fold_bits = i0 > i1 ? i0 : i1;
+                }
+#pragma unroll
+                for (int u = 0; u < decltype(N0C)::value; ++u) {  // (a, d) of this thread's channels of chunk 0, straight into registers
+                    const GroupOf o = group_of(s_g[u] * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float2 e0 = gn_affine(o.mo, wfix(wu[u][j >> 1][2 * (j & 1)]), hu[u][j >> 1][2 * (j & 1)]);
+                        const float2 e1 = gn_affine(o.mo, wfix(wu[u][j >> 1][2 * (j & 1) + 1]), hu[u][j >> 1][2 * (j & 1) + 1]);
+                        ad4[u][j] = f32x4{e0.x, e0.y, e1.x, e1.y};
+                    }
+                }
+                if (p.gn_range) {  // the block's bound: one value per wave now, one conditional atomic per block behind P
+                    fold_bits = wave_max_i32(fold_bits);
+                    if (lane == 0) reinterpret_cast<int*>(scr + 96)[wave] = fold_bits;  // (scr[96 .. 98): behind the [8][4][3] totals, in front of the moment rows at scr + 104)
+                }
+            } else
+                load_next(set0, N0C);
+            if (PRO != PRO_NONE && !fold) {
                 int cot0, b0, th0, tw0;
                 decode(0, cot0, b0, th0, tw0);
                 const unsigned char* a0 = sbase(reinterpret_cast<const float*>(p.aff) + (size_t)b0 * p.Cin * 2);
@@ -600,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) gload(ad4[u][j], a0 + 16 * j, (unsigned)s_g[u] * 64u);
             }
-            table_fetch(0);
+            if (!fold) table_fetch(0);
             stamp(31);
             dma_stage(0, ic<0>{});
             dma_stage(0, ic<1>{});
@@ -621,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             transform_half(set0, N0C, 1, smem, false);
             x_c = 1;
             stamp(33);
-            table_store(ic<RING_NEWER + NL1>{});  // (all stagers write their part of the first tile's table: published by P)
+            if (!fold) table_store(ic<RING_NEWER + NL1>{});  // (all stagers write their part of the first tile's table: published by P)
             load_next(set0, N0C);                 // chunk 2 (the cursor saturates: harmless for a one-tile, two-chunk block)
             // P needs the ring stages and this wave's x writes; the pixels of chunk 1 may still be on their way -- iteration 0 waits for
             // them itself (the multipliers get to their first taps that much earlier)
@@ -630,6 +769,13 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             __builtin_amdgcn_s_barrier();  // P
             stamp(35);
             asm volatile("" ::: "memory");
+            if (PRO != PRO_NONE && fold && p.gn_range && wave == 0 && lane == 0) {  // (the four waves' bounds were published by P)
+                const int* wb = reinterpret_cast<const int*>(reinterpret_cast<const double*>(smem + RES0) + 96);
+                int bits = wb[0] > wb[1] ? wb[0] : wb[1];
+                bits = wb[2] > bits ? wb[2] : bits;
+                bits = wb[3] > bits ? wb[3] : bits;
+                if (bits > __atomic_load_n(p.gn_range + 1, __ATOMIC_RELAXED)) atomicMax(p.gn_range + 1, bits);
+            }
 
             // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
             // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
@@ -646,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
                 const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
                 const bool bias_now = EPI2 && x_c == 1;  // (nchunks >= 4: never the iteration of the table fetch or store)
-                if (fetch) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
+                if (fetch && !fold) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
                 if (bias_now) bias_fetch();          // (likewise)
                 dma_stage(3 * q, ic<RING - 1>{});    // D0
                 if (q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLp + PPW) : "memory");  // (only chunk 2 and D0 are younger than chunk 1)
@@ -667,7 +813,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 stamp(15);
                 asm volatile("" ::: "memory");
                 if (last_of_tile) {                  // the next transform belongs to the next tile: its table (fetched at the start
-                    table_store(ic<5 * PPW + NLp>{});  // of the previous iteration) goes to LDS
+                    if (!fold) table_store(ic<5 * PPW + NLp>{});  // of the previous iteration) goes to LDS
                     ++t_item;
                 }
                 if (bias_now) bias_store(ic<2 * PPW>{});  // (fetched at this iteration's start: D0 and D1 are younger; published by #3)
@@ -1297,6 +1443,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         }
     };
 
+    if (PRO != PRO_NONE && p.gn_partial != nullptr) __builtin_amdgcn_s_barrier();  // P0 of the folded GroupNorm (stagers only work there)
     stamp(36);
     __builtin_amdgcn_s_barrier();  // P: ring stages 0..RING-2 and chunk 0 staged
     stamp(37);
@@ -1476,10 +1623,36 @@ static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// GroupNorm folded into this launch?  8 groups of 8 .. 64 channels over exactly the input channels, at most 4 x 256 statistics slots per
+// group to read (the fold keeps them in registers: beyond that the separate gn_finalize launch is the faster way -- 128 x 2048 level 1), and
+// every block's tiles inside ONE sample (the table is computed once per block) -- true at batch 8 / 2 / 1 for every layer of the network,
+// checked here for whatever else arrives.
+bool conv_f16x2_fold_supported(const ConvParams& p, int groups, int slots) {
+    const char* fe = getenv("R2DM_GN_FOLD");  // (R2DM_GN_FOLD=0: experiments, A/B, the bit-identity test; read per call)
+    const bool fold_on = !fe || atoi(fe) != 0;
+    if (!fold_on || groups != 8 || p.Cin % 8 || slots < 1 || slots > 4 * 256) return false;
+    const int cpg = p.Cin / 8;
+    if (cpg < 8 || cpg > 64 || (cpg & (cpg - 1))) return false;
+    if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile, p.px_rows) || p.prologue == PRO_NONE || p.prologue == PRO_PRESPLIT) return false;
+    const long tps = (long)(p.Cout / p.co_tile) * (p.W / f2::TW) * (p.H / p.px_rows), tiles = tps * p.B;
+    const int n_cu = f2_cu_count();
+    if (tiles <= n_cu) return true;  // one tile per block
+    if (getenv("R2DM_F2_NONPERSISTENT")) return true;
+    const int G = n_cu;
+    for (int blk = 0; blk < G; ++blk) {
+        const long nIt = (tiles - blk + G - 1) / G;
+        long l0 = xcd_remap(blk, (int)tiles), l1 = xcd_remap((int)(blk + (nIt - 1) * G), (int)tiles);
+        if (p.reverse) { l0 = tiles - 1 - l0; l1 = tiles - 1 - l1; }
+        if (l0 / tps != l1 / tps) return false;  // (a block's tile indices are monotonic: the first and the last bound the rest)
+    }
+    return true;
+}
+
 hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
     if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile, p.px_rows)) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
-    if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr) return hipErrorInvalidValue;
+    if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr && p.gn_partial == nullptr) return hipErrorInvalidValue;
+    if (p.gn_partial && (p.aff != nullptr || p.gn_cpg * 8 != p.Cin || !conv_f16x2_fold_supported(p, 8, p.gn_slots))) return hipErrorInvalidValue;
     if (p.prologue == PRO_PRESPLIT && (p.co_tile != 64 || p.px_rows != 4 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
 #ifndef F2_PROF
     if (p.prof != nullptr) return hipErrorInvalidValue;

@@ -464,10 +464,36 @@ struct Ctx {
         return aff;
     }
 
+    // The GroupNorm in front of a convolution: the statistics its producers left (or not: the streaming pass) and its parameters.
+    // conv() with a NormSpec runs the norm itself -- folded into the convolution's staging waves where conv_f16x2.hip can do that (no
+    // gn_finalize launch: 45 of the 50 GroupNorms of a forward at batch 8), else as the separate launch(es) in front of it.
+    struct NormSpec {
+        const Sink* stats;
+        const float *gamma, *beta, *ada;
+    };
+
     Tensor conv(const ConvLayer& L, const Src& x, int H, int W, int pro, const float2* aff, const Tensor* res,
                 size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0,
                 bool res_broadcast = false, bool input_bounded = false,  // input_bounded: its producer tracked max|x| in the range flag
-                bool track_out = false) {                               // track_out: record max|y| there (precision mode 2 only)
+                bool track_out = false,                                 // track_out: record max|y| there (precision mode 2 only)
+                const NormSpec* ns = nullptr) {                         // ns: `aff` comes from this GroupNorm (aff must be nullptr)
+        // (decided in the dry walk as well, from shapes and the batch alone: the allocation sequence must be the same in both walks)
+        bool fold = false;
+        float2* own_aff = nullptr;
+        if (ns) {
+            const Sink& k = *ns->stats;
+            const int G = h->cfg.gn_num_groups;
+            if (k && L.f2 && h->f16_path() && k.C == L.cin && G == 8) {
+                ConvParams q;
+                q.Cin = L.cin; q.Cout = L.cout; q.taps = L.taps; q.H = H; q.W = W; q.co_tile = L.f2_cot; q.px_rows = L.f2_rows; q.B = B; q.prologue = pro;
+                const int slots = k.cpg < 64 ? k.slots / 2 : k.slots;  // (groups of fewer than 64 channels leave the second half of their slots zero)
+                q.reverse = 0;
+                fold = conv_f16x2_fold_supported(q, G, slots);
+                q.reverse = 1;  // (whichever direction this launch will walk its tiles in)
+                fold = fold && conv_f16x2_fold_supported(q, G, slots);
+            }
+            if (!fold) aff = own_aff = norm(k, x, H, W, ns->gamma, ns->beta, ns->ada);
+        }
         Tensor y;
         y.C = L.cout;
         y.H = H;
@@ -485,7 +511,7 @@ struct Ctx {
         static const int presplit_min_cout = getenv("R2DM_F2_PRESPLIT_MIN_COUT") ? atoi(getenv("R2DM_F2_PRESPLIT_MIN_COUT")) : 0;  // (0: never)
         const bool f2_launch = L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded);
         float* xs = nullptr;
-        if (f2_launch && L.f2_cot == 64 && L.f2_rows == 4 && presplit_min_cout > 0 && L.cout >= presplit_min_cout && presplit_supported(x, L.cin, H, W))
+        if (f2_launch && !fold && L.f2_cot == 64 && L.f2_rows == 4 && presplit_min_cout > 0 && L.cout >= presplit_min_cout && presplit_supported(x, L.cin, H, W))
             xs = (float*)ar->alloc((size_t)presplit_floats(B, L.cin, H, W) * sizeof(float));
         if (!dry()) {
             ConvParams p;
@@ -520,6 +546,19 @@ struct Ctx {
                 p.co_tile = L.f2_cot;
                 p.px_rows = L.f2_rows;
                 p.pieces = h->conv_pieces;
+                if (fold) {
+                    const Sink& k = *ns->stats;
+                    p.gn_partial = k.p;
+                    p.gn_stride = k.slots;
+                    p.gn_slots = k.cpg < 64 ? k.slots / 2 : k.slots;
+                    p.gn_cpg = k.cpg;
+                    p.gn_eps = h->cfg.gn_eps;
+                    p.gn_gamma = ns->gamma;
+                    p.gn_beta = ns->beta;
+                    p.gn_ada = ns->ada;
+                    p.gn_ada_stride = (long)h->ada_rows;
+                    p.gn_range = (int*)blob(h->range_flag);
+                }
             }
             // deep layers (many 64-channel output tiles): the input transform once, by the pre-pass (presplit.hip)
             if (xs) {
@@ -574,6 +613,7 @@ struct Ctx {
             if (e1) (void)hipEventRecord(e1, st);
         }
         if (xs) ar->release(xs);  // (stream-ordered: the next user of that memory is enqueued behind this convolution)
+        if (own_aff) ar->release(own_aff);
         return y;
     }
 
@@ -581,12 +621,10 @@ struct Ctx {
     // `out` / `out_goff`: where the statistics of this block's output go (the next GroupNorm's sink).
     Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,
                           bool track_out = false, bool skip_bounded = false) {
-        float2* a1 = norm(in_stats, x, H, W, blob(r.g1), blob(r.b1), nullptr);
+        const NormSpec n1{&in_stats, blob(r.g1), blob(r.b1), nullptr};
         Sink s1 = make_sink(r.cout, H, W);
-        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, a1, nullptr, 0, false, nullptr, &s1, 0);
-        ar->release(a1);
-        float2* a2 = norm(s1, src1(t1), H, W, nullptr, nullptr, proj + r.ada_row);
-        drop_sink(s1);
+        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, nullptr, nullptr, 0, false, nullptr, &s1, 0, false, false, false, &n1);
+        const NormSpec n2{&s1, nullptr, nullptr, proj + r.ada_row};
         Tensor skip;
         const Tensor* res;
         Tensor ident;
@@ -600,8 +638,8 @@ struct Ctx {
             ident.W = W;
             res = &ident;
         }
-        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, a2, res, r.scale, true, nullptr, out, out_goff, false, false, track_out);
-        ar->release(a2);
+        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, nullptr, res, r.scale, true, nullptr, out, out_goff, false, false, track_out, &n2);
+        drop_sink(s1);
         drop(t1);
         if (r.has_skip) drop(skip);
         return o;
@@ -977,9 +1015,10 @@ int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces) {
     if (pieces < 1 || pieces > 3)
         return fail(1, "pieces must be 2 (fp16 + scaled fp16 residual: the default parity mode), 3 (three bf16 pieces: fp32 operand range) or "
                        "1 (one fp16 product per MAC: reduced precision)");
-    if (h)
+    if (h) {
         h->conv_pieces = pieces;
-    else
+        h->ws_cache.clear();  // (the walk's allocation sequence depends on the mode -- folded GroupNorms, the pre-pass scratch)
+    } else
         g_single_kernel_pieces = pieces;
     return 0;
 }

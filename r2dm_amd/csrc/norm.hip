@@ -12,6 +12,7 @@
 // (fp64 VALU is not a bottleneck on a streaming kernel and makes E[x^2]-E[x]^2 safe for groups of
 // up to 2^22 elements), wavefront shuffle reduce, fixed-order cross-block combine => deterministic.
 #include "common.h"
+#include "gn_math.h"
 #include "wave_ops.h"
 
 namespace r2dm {
@@ -122,8 +123,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     if (range_flag && !partial_max) gmax = wave_max_f32((float)sqrt(emax) * 1.000001f);
     __shared__ double red[2][4];
     __shared__ float redm[4];
-    sum = wave_sum(sum);
-    sq = wave_sum(sq);
+    // (the reduction order from here on is a contract with the consumer-side fold in conv_f16x2.hip: per-thread partials over slots
+    // t, t + 256, ... ascending; wave_sum_f64_hi_first; the four waves as (w0 + w1) + (w2 + w3))
+    sum = wave_sum_f64_hi_first(sum);
+    sq = wave_sum_f64_hi_first(sq);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = sum;
         red[1][threadIdx.x >> 6] = sq;
@@ -133,12 +136,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     gmax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    // (the arithmetic from here on is gn_math.h's: conv_f16x2.hip's consumer-side fold repeats it bit for bit)
     const double n = (double)cpg * (double)hw;
-    const double mean_d = sum / n;
-    double var_d = sq / n - mean_d * mean_d;
-    var_d = var_d > 0.0 ? var_d : 0.0;
-    const float mean = (float)mean_d;
-    const float rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    const GnMoments mo = gn_moments(sum, sq, n, eps);
+    const float mean = mo.mean, rstd = mo.rstd;
     if (stats && threadIdx.x == 0) {
         stats[((long)b * G + g) * 2 + 0] = mean;
         stats[((long)b * G + g) * 2 + 1] = rstd;
@@ -153,22 +154,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
             w = gamma ? gamma[c] : 1.0f;
             sh = beta ? beta[c] : 0.0f;
         }
-        const float a = rstd * w;
-        aff[(long)b * C + c] = make_float2(a, sh - mean * a);
-        // Range guard of the fp16 consumers: a bound on |a x + d| over the group, |a| M + |d| with M >= max|x| from the data:
-        // the producers' recorded maximum, or else the square root of the largest slot energy (above).  SiLU only shrinks it.
-        // (recorded as a running maximum -- positive floats order like their bit patterns, NaN above all -- and compared
-        // with the fp16 limit by r2dm_check_range)
-        if (range_flag) {
-            const float d = sh - mean * a;
-            // ... or, where that one is looser (a near-constant group: large |mean| / sigma makes |a| M and |d| both huge although
-            // they cancel), the worst-case bound on a normalised value, |x_hat| <= sqrt(n - 1) (Samuelson): |w| sqrt(n) + |sh|.
-            // Both are rigorous; the smaller one is recorded (never looser than round 2's guard)
-            const float data_bound = fabsf(a) * gmax + fabsf(d);
-            const float worst_bound = (fabsf(w) * (float)sqrt(n) + fabsf(sh)) * 1.000001f;
-            const float bound = data_bound > worst_bound ? worst_bound : data_bound;  // (a NaN data bound stays: the comparison is false)
-            atomicMax(range_flag + 1, __float_as_int(bound));
-        }
+        const float2 ad = gn_affine(mo, w, sh);
+        aff[(long)b * C + c] = ad;
+        // Range guard of the fp16 consumers (gn_math.h: gn_bound): recorded as a running maximum -- positive floats order like their
+        // bit patterns, NaN above all -- and compared with the fp16 limit by r2dm_check_range.  SiLU only shrinks the bound.
+        if (range_flag) atomicMax(range_flag + 1, __float_as_int(gn_bound(mo, ad, w, sh, gmax, n)));
     }
 }
 

@@ -56,6 +56,18 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     wave_swap_add(v, v, false);
     return v;
 }
+// the same total with the exchange steps in the order of wave_sum8_scatter below (lane ^ 32, ^ 16, ^ 8, then inside the 8): the order
+// gn_finalize_kernel sums a group's 256 per-thread partials in, so that conv_f16x2.hip's folded GroupNorm -- which reduces all eight groups
+// at once with the reduce-scatter -- gets the same bits
+__device__ __forceinline__ double wave_sum_f64_hi_first(double v) {
+    wave_swap_add(v, v, false);
+    wave_swap_add(v, v, true);
+    v += wave_dpp<0x128>(v);
+    v += wave_dpp<0xB1>(v);
+    v += wave_dpp<0x4E>(v);
+    v += wave_dpp<0x141>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, wave_dpp<0xB1>(v));
     v = fmaxf(v, wave_dpp<0x4E>(v));
@@ -65,6 +77,19 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
+// maximum of non-negative float bit patterns / ints over the wave (NaN patterns sort above infinity and survive, unlike fmaxf)
+__device__ __forceinline__ int wave_max_i32(int v) {
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false));
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = mx((int)r[0], (int)r[1]);
+    const auto t = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return mx((int)t[0], (int)t[1]);
 }
 
 // Eight values at once as a butterfly reduce-scatter (4 + 2 + 1 exchange steps halve the live values, three more finish the

@@ -382,3 +382,31 @@ def test_repaint_keeps_known_region_statistics(small):
     out = ddpm.repaint(known, half, num_steps=4, num_resample_steps=2, progress=False, return_all=True)
     assert out.shape[0] == 1 + 4 * 2 - 1 and torch.isfinite(out).all()
     assert max_abs(out[-1][..., : GOLDEN_RES[1] // 2], known[..., : GOLDEN_RES[1] // 2]) < 5e-3
+
+
+@pytest.mark.parametrize("res,batch", [((64, 1024), 8), ((64, 1024), 3), ((128, 2048), 2)])
+def test_group_norm_folded_into_its_consumer_is_bit_identical(res, batch):
+    """gn_finalize folded into the consuming convolution (conv_f16x2.hip: the staging waves of every block reduce the
+    producers' statistics slots of the block's sample while the first pixels are on their way).  The fold repeats gn_finalize_kernel's reduction
+    order and arithmetic (gn_math.h), so a forward with it (default) and without it (R2DM_GN_FOLD=0: the separate launches) must agree bit for bit
+    -- at batch 8 (every block inside one sample: 45 of 50 norms folded), at batch 3 (some launches refuse the fold) and at 128x2048 (level 1 has
+    too many slots and keeps the separate launch).  The range guard's bound travels the same way: a gain outside the fp16 range trips it
+    (tests/test_hip_range.py run with the fold on)."""
+    import r2dm_amd
+
+    ck = synthetic_ckpt(resolution=res)
+    x, c = rnd(7, batch, 2, *res).to(DEV), torch.linspace(-4.0, 6.0, batch).to(DEV)
+    outs = {}
+    saved = os.environ.get("R2DM_GN_FOLD")
+    for mode in ("1", "0"):
+        os.environ["R2DM_GN_FOLD"] = mode
+        try:
+            m, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=batch)
+            outs[mode] = (m.model(x, c).clone(), m.model(x, c).clone())
+            del m
+        finally:
+            os.environ.pop("R2DM_GN_FOLD", None)
+            if saved is not None:
+                os.environ["R2DM_GN_FOLD"] = saved
+    assert torch.equal(outs["1"][0], outs["1"][1]) and torch.equal(outs["0"][0], outs["0"][1])
+    assert torch.equal(outs["1"][0], outs["0"][0])

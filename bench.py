@@ -77,18 +77,19 @@ def cpu_baseline(ck, cf):
     torch.set_num_threads(cores)
     O, net = oracle_net(ck, cf["res"], "cpu")
     rng = [torch.Generator().manual_seed(0)]
-    n = 16 if cf["res"] == (64, 1024) else 4
+    n = 8 if cf["res"] == (64, 1024) else 4  # (64x1024: BASELINE configs[0] literally -- batch 1, 8 DDPM steps)
     with torch.inference_mode():
         O.sample_continuous(net, (1, 2, *cf["res"]), 1, rng=rng, mode=cf["mode"])  # warm-up
         t0 = time.perf_counter()
         O.sample_continuous(net, (1, 2, *cf["res"]), n, rng=rng, mode=cf["mode"])
         dt = time.perf_counter() - t0
     return {"value": 1.0 / (dt / n * cf["sampler_steps"]), "unit": "images/s", "cores": cores, "kind": "port",
+            "configs0_seconds": dt if n == 8 and cf["mode"] == "ddpm" else None,  # wall time of BASELINE configs[0] itself (8-step DDPM, batch 1)
             "sample": f"oracle (torch CPU ops, fp32) sample(batch=1, {n} {cf['mode'].upper()} steps) at {cf['res'][0]}x{cf['res'][1]} on "
                       f"{cores} threads of {os.cpu_count()} host cores, {dt / n:.3f} s/step, scaled to the {cf['sampler_steps']}-step sampler"}
 
 
-def torch_rocm_baseline(ck, cf, B, dev):
+def torch_rocm_baseline(ck, cf, B, dev, compiled=True, compile_budget_s=240):
     """The same oracle evaluated by stock PyTorch-ROCm on the MI355X (MIOpen convolutions, rocBLAS attention), fp32,
     same batch: what running the reference's PyTorch sampler on this GPU costs.  One warm-up step (MIOpen kernel
     selection), then a bounded number of steps timed with a device synchronize on both sides."""
@@ -121,6 +122,35 @@ def torch_rocm_baseline(ck, cf, B, dev):
                                 "kind": "the same oracle under torch.autocast(fp16), eager"}
     except Exception as e:  # (an autocast path MIOpen cannot serve must not take the line down)
         out["fp16_autocast"] = {"error": repr(e)[:200]}
+    # ... and the form the reference's bulk script REALLY runs (sample_and_save.py:45,70): the denoiser through torch.compile (inductor)
+    # under fp16 autocast.  Compilation is bounded (a watchdog ends it: the default bench run has minutes, not an hour).
+    if compiled:
+        import signal
+
+        def _alarm(*_):
+            raise TimeoutError("torch.compile did not finish inside the watchdog")
+
+        old = signal.signal(signal.SIGALRM, _alarm)
+        signal.alarm(int(compile_budget_s))
+        try:
+            t_c = time.perf_counter()
+            cnet = torch.compile(net)
+            canet = lambda x, c: torch.autocast("cuda", dtype=torch.float16)(cnet)(x, c).float()
+            with torch.inference_mode():
+                O.sample_continuous(canet, shape, 1, rng=rng, mode=cf["mode"], device=dev)
+                torch.cuda.synchronize()
+                compile_s = time.perf_counter() - t_c
+                t0 = time.perf_counter()
+                O.sample_continuous(canet, shape, n, rng=rng, mode=cf["mode"], device=dev)
+                torch.cuda.synchronize()
+                dtc = time.perf_counter() - t0
+            out["compiled_fp16_autocast"] = {"value": B / (dtc / n * cf["sampler_steps"]), "unit": "images/s", "ms_per_step": dtc / n * 1e3, "compile_s": compile_s,
+                                             "kind": "the same oracle through torch.compile (inductor) under torch.autocast(fp16): how /root/reference/sample_and_save.py:45,70 runs the denoiser"}
+        except BaseException as e:  # (incl. the watchdog; a compile failure must not take the line down)
+            out["compiled_fp16_autocast"] = {"error": repr(e)[:300]}
+        finally:
+            signal.alarm(0)
+            signal.signal(signal.SIGALRM, old)
     return out
 
 
@@ -221,6 +251,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[2] and configs[4] that ride on the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
+    ap.add_argument("--no-compile-baseline", action="store_true", help="skip the torch.compile + fp16 autocast form of the PyTorch-ROCm baseline (its compilation takes a minute or two)")
     ap.add_argument("--precision", choices=["fp32", "fp32-bf16x3", "fp16"], default="fp32",
                     help="arithmetic of the convolutions / attention on the matrix pipe (unet.py set_precision).  fp32 (default) and "
                          "fp32-bf16x3 are parity modes: 22-bit fp16 split, 3 products / exact 24-bit bf16 split, 6 products.  fp16 is the "
@@ -255,6 +286,8 @@ def main():
     ddpm.to(dev)
     broadcast_packed_weights(ddpm.model, dev, src=0)  # rank 0 packs, everyone else adopts the blob
     seeds = shard_seeds(list(range(args.seed_base, args.seed_base + B * world)), rank, world)
+    from r2dm_amd.distributed import collective_report
+    rccl = collective_report(ddpm.model, dev)  # N > 1: backend, world size, and one all-reduce proving every rank holds the same blob
 
     def run(steps):
         return ddpm.sample(batch_size=B, num_steps=steps, progress=False, mode=cf["mode"], rng=r2dm_amd.setup_rng(seeds, dev))
@@ -354,6 +387,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 operands, f32 accumulation / tensors (reduced-precision bulk mode: NOT the parity path)" if args.precision == "fp16" else "f32",
+            "arithmetic": {"fp32": "fp32 tensors and accumulation; matrix products on 22-bit split fp16 operands (3 MFMA products per fp32 product)",
+                           "fp32-bf16x3": "fp32 tensors and accumulation; matrix products on exact 24-bit split bf16 operands (6 MFMA products per fp32 product)",
+                           "fp16": "fp32 tensors and accumulation; matrix products on fp16 operands (1 product): reduced precision"}[args.precision],
             "data": "synthetic",
             "config": {"workload": cf["workload"] + f"; timed = one sample() call of --steps reverse steps, value scaled to {S} steps",
                        "baseline_config": args.config, "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
@@ -376,6 +412,8 @@ def main():
         line["roofline"] = {
             "bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": pmc_traffic() if args.config == 1 else None,
+            "traffic_source": "replayed: profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, round 4; PMC counters "
+                              "cannot be collected inside the timed process)" if args.config == 1 else None,
             "peak_definition": "dominant kernel %s: dense 16-bit MFMA peak 2500 TF/s (2.4 GHz) / %d matrix products per algorithmic "
                                "fp32 product" % (dom["kernel"], dom.get("products_per_fp32_product", 1)),
             "frac_of_round1_peak": dom["tflops"] / (PEAK_BF16 / 6 / 1e12),  # round 1 priced the same algorithmic FLOPs at 2500/6 = 416.7 TF/s
@@ -399,7 +437,7 @@ def main():
         if world == 1 and not args.no_torch_baseline:
             line["roofline"]["hipblaslt_bf16_gemm"] = hipblaslt_reference(dev)
         if world == 1 and not args.no_torch_baseline:
-            tb = torch_rocm_baseline(ck, cf, B, dev)
+            tb = torch_rocm_baseline(ck, cf, B, dev, compiled=not args.no_compile_baseline)
             tb["speedup"] = value / tb["value"]
             line["torch_rocm_baseline"] = tb
             # north_star: ">= N x the reference single-GPU PyTorch sampler" -- BASELINE.md has no published number for this
@@ -412,6 +450,12 @@ def main():
                 if args.precision == "fp16":  # the reduced mode is compared with the reference's reduced mode
                     line["vs_baseline"] = value / ac["value"]
                     line["vs_baseline_definition"] = "value / torch_rocm_baseline.fp16_autocast.value (the reference's fp16-autocast bulk mode on this GPU, same run)"
+            cc = tb.get("compiled_fp16_autocast", {})
+            if "value" in cc:
+                cc["speedup"] = value / cc["value"]
+                if args.precision == "fp16" and cc["value"] > ac.get("value", 0.0):  # (against the FASTER form of the reference's bulk mode)
+                    line["vs_baseline"] = value / cc["value"]
+                    line["vs_baseline_definition"] = "value / torch_rocm_baseline.compiled_fp16_autocast.value (torch.compile + fp16 autocast: the reference's bulk sampler as sample_and_save.py runs it, same run)"
         if world == 1 and not args.no_exact_baseline and args.precision == "fp32":
             ddpm.model.set_precision("fp32-bf16x3")
             prewarm(1.0)
@@ -456,6 +500,7 @@ def main():
                 del om
                 torch.cuda.empty_cache()
             line["other_configs"] = others
+        line["rccl"] = rccl
         print(json.dumps(line))
     if dist:
         td.destroy_process_group()

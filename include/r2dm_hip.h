@@ -67,6 +67,12 @@ void r2dm_destroy(r2dm_handle* h);
 int64_t r2dm_num_tensors(const r2dm_handle* h);
 int r2dm_tensor_at(const r2dm_handle* h, int64_t index, r2dm_tensor_info* out);
 size_t r2dm_blob_bytes(const r2dm_handle* h);
+
+/* Fingerprint of the blob's LAYOUT as this handle planned it: every slot's key, offset and packing (algorithm, channel / pixel tile of
+ * each convolution's packings -- they depend on max_batch, the device's CU count and experiment switches, not only on the
+ * configuration) and the blob size.  A blob filled through one handle may be bound by another only if the two agree (the Python
+ * wrapper compares them before it adopts a broadcast blob: a mismatch would run silently wrong convolutions -- ADVICE round 4). */
+uint64_t r2dm_blob_layout_hash(const r2dm_handle* h);
 int r2dm_bind_blob(r2dm_handle* h, void* dev_blob, size_t bytes);
 int r2dm_load_tensor(r2dm_handle* h, int64_t index, const float* dev_src, int64_t numel, void* stream);
 

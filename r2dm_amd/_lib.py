@@ -62,6 +62,7 @@ SIGNATURES = {
     "r2dm_num_tensors": (c_int64, [_P]),
     "r2dm_tensor_at": (c_int32, [_P, c_int64, POINTER(TensorInfo)]),
     "r2dm_blob_bytes": (c_size_t, [_P]),
+    "r2dm_blob_layout_hash": (ctypes.c_uint64, [_P]),
     "r2dm_bind_blob": (c_int32, [_P, _P, c_size_t]),
     "r2dm_load_tensor": (c_int32, [_P, c_int64, _P, c_int64, _P]),
     "r2dm_workspace_bytes": (c_size_t, [_P, c_int32]),

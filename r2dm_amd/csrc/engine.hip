@@ -872,6 +872,35 @@ int r2dm_tensor_at(const r2dm_handle* h, int64_t i, r2dm_tensor_info* out) {
 
 size_t r2dm_blob_bytes(const r2dm_handle* h) { return h ? h->blob_floats * sizeof(float) : 0; }
 
+uint64_t r2dm_blob_layout_hash(const r2dm_handle* h) {
+    if (!h) return 0;
+    uint64_t v = 1469598103934665603ull;  // FNV-1a over the plan
+    auto mix = [&](uint64_t x) {
+        for (int i = 0; i < 8; ++i) {
+            v ^= (x >> (8 * i)) & 0xff;
+            v *= 1099511628211ull;
+        }
+    };
+    mix(h->blob_floats);
+    mix(h->range_flag);
+    mix(h->cmap);
+    mix(h->ada_w);
+    mix(h->ada_b);
+    for (const Slot& s : h->slots) {
+        for (char c : s.key) mix((unsigned char)c);
+        mix((uint64_t)s.numel);
+        mix((uint64_t)s.kind);
+        mix(s.off);
+        if (s.kind == SLOT_CONV) {
+            const ConvLayer& L = s.conv;
+            const uint64_t f[] = {(uint64_t)L.cin, (uint64_t)L.cout, (uint64_t)L.taps, (uint64_t)L.co_tile, (uint64_t)L.cin_pad, (uint64_t)L.algo, (uint64_t)L.src_cin,
+                                  (uint64_t)L.src_off, L.w, L.b, (uint64_t)L.f2, (uint64_t)L.f2_cot, (uint64_t)L.f2_rows, L.w_f2, L.ws_f2, (uint64_t)L.p1, L.w_p1, L.ws_p1};
+            for (uint64_t x : f) mix(x);
+        }
+    }
+    return v;
+}
+
 int r2dm_bind_blob(r2dm_handle* h, void* blob, size_t bytes) {
     if (!h || !blob) return fail(1, "null argument");
     if (bytes < r2dm_blob_bytes(h)) return fail(1, "blob too small: %zu < %zu", bytes, r2dm_blob_bytes(h));

@@ -45,6 +45,8 @@ def broadcast_packed_weights(model, device, src: int = 0) -> None:
         model.packed_weights(device)
         return
     on_host = td.get_backend() != "nccl"
+    meta = [model.packed_layout_hash() if td.get_rank() == src else None]
+    td.broadcast_object_list(meta, src=src)  # (the layout the blob was packed for: checked by every adopter)
     if td.get_rank() == src:
         blob = model.packed_weights(device)
         wire = blob.cpu() if on_host else blob
@@ -52,7 +54,31 @@ def broadcast_packed_weights(model, device, src: int = 0) -> None:
         wire = torch.empty(model.packed_weight_bytes(), dtype=torch.uint8, device="cpu" if on_host else device)
     td.broadcast(wire, src=src)
     if td.get_rank() != src:
-        model.adopt_packed_weights(wire.to(device) if on_host else wire)
+        model.adopt_packed_weights(wire.to(device) if on_host else wire, layout_hash=meta[0])
+
+
+def blob_checksum(blob: torch.Tensor) -> int:
+    """A 63-bit checksum of a packed weight blob (wrapping sum of its 8-byte words, computed where the blob lives)."""
+    n = blob.numel() // 8 * 8
+    words = blob[:n].view(torch.int64)
+    tail = int(blob[n:].to(torch.int64).sum().item()) if n < blob.numel() else 0
+    return (int(words.sum().item()) + tail) & 0x7FFFFFFFFFFFFFFF
+
+
+def collective_report(model=None, device=None) -> dict:
+    """What a multi-GPU line must prove: which backend ran, over how many ranks, and that every rank samples
+    from the SAME weights -- one all-reduce (MIN and MAX) of the adopted blob's checksum over the job's process group (RCCL over xGMI
+    under "nccl").  Single process: world_size 1, no collective."""
+    td = _dist()
+    if td is None or td.get_world_size() == 1:
+        return {"backend": None, "world_size": 1, "blob_crc_equal_on_all_ranks": None}
+    crc = blob_checksum(model.packed_weights(device)) if model is not None else 0
+    on_host = td.get_backend() != "nccl"
+    t = torch.tensor([crc, -crc], dtype=torch.int64, device="cpu" if on_host else device)
+    td.all_reduce(t, op=td.ReduceOp.MIN)  # (min(crc), min(-crc) = -max(crc))
+    lo, hi = int(t[0].item()), -int(t[1].item())
+    return {"backend": td.get_backend() + (" (RCCL)" if td.get_backend() == "nccl" else ""), "world_size": td.get_world_size(),
+            "blob_crc_equal_on_all_ranks": lo == hi == crc, "blob_crc": crc}
 
 
 def sample_sharded(sample_fn: Callable[[List[int]], torch.Tensor], seeds: Sequence[int], gather: bool = True,

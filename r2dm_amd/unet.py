@@ -102,6 +102,9 @@ class _Engine:
     def blob_bytes(self) -> int:
         return int(_lib.lib().r2dm_blob_bytes(self.h))
 
+    def layout_hash(self) -> int:
+        return int(_lib.lib().r2dm_blob_layout_hash(self.h))
+
     def bind(self, blob: torch.Tensor):
         _lib.require_gpu(blob, "weight blob")
         assert blob.dtype == torch.uint8 and blob.is_contiguous()
@@ -245,12 +248,27 @@ class EfficientUNet(nn.Module):
         self._ensure_packed(device)
         return self._engine.blob
 
-    def adopt_packed_weights(self, blob: torch.Tensor):
-        """Bind a blob produced by ``packed_weights()`` of an identically configured model
-        (e.g. received through ``torch.distributed.broadcast``) without loading a state dict."""
+    def packed_layout_hash(self) -> int:
+        """Fingerprint of the blob layout THIS model's engine plans (r2dm_blob_layout_hash): the packings depend on ``max_batch``, the
+        device's CU count and experiment switches, not only on the configuration -- a blob may only be adopted between equal layouts."""
         if self._engine is None:
             self._engine = _Engine(self.geometry, self.max_batch)
             self.set_precision(self.precision)
+        return self._engine.layout_hash()
+
+    def adopt_packed_weights(self, blob: torch.Tensor, layout_hash: Optional[int] = None):
+        """Bind a blob produced by ``packed_weights()`` of an identically configured model
+        (e.g. received through ``torch.distributed.broadcast``) without loading a state dict.  ``layout_hash``: the packing
+        model's ``packed_layout_hash()`` -- checked against this model's (the byte count alone cannot tell a blob
+        planned for another batch size or tile choice, whose convolutions would then be silently wrong)."""
+        if self._engine is None:
+            self._engine = _Engine(self.geometry, self.max_batch)
+            self.set_precision(self.precision)
+        if layout_hash is None and blob.numel() != self._engine.blob_bytes():
+            raise _lib.R2DMError(f"blob has {blob.numel()} bytes, engine expects {self._engine.blob_bytes()}")
+        if layout_hash is not None and int(layout_hash) != self._engine.layout_hash():
+            raise _lib.R2DMError(f"blob layout {int(layout_hash):#x} does not match this model's {self._engine.layout_hash():#x}: it was packed for another "
+                                 "max_batch / device / tile selection (the packings of the convolutions differ); pack it with the same setup_model arguments")
         if blob.numel() != self._engine.blob_bytes():
             raise _lib.R2DMError(f"blob has {blob.numel()} bytes, engine expects {self._engine.blob_bytes()}")
         self._engine.bind(blob)

@@ -79,6 +79,55 @@ def test_two_ranks_match_single_process(tmp_path, seeds):
     assert torch.equal(got, want)  # partition-invariant: per-seed generators, no cross-sample coupling
 
 
+def _worker8(rank, world, port, seeds, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+
+    from r2dm_amd import distributed as D
+
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        blob = torch.zeros(4096, dtype=torch.uint8)
+        if rank == 0:
+            blob = torch.randn(1024, generator=torch.Generator().manual_seed(42)).view(torch.uint8).clone()
+        D.broadcast_tensor(blob, src=0)
+
+        class Holder:  # what collective_report needs of a model: the adopted blob
+            def packed_weights(self, device):
+                return blob
+
+        rep = D.collective_report(Holder(), "cpu")
+        assert rep["world_size"] == world and rep["backend"].startswith("gloo") and rep["blob_crc_equal_on_all_ranks"] is True
+        bad = D.collective_report(type("H", (), {"packed_weights": lambda self, d: blob + (1 if rank == world - 1 else 0)})(), "cpu")
+        assert bad["blob_crc_equal_on_all_ranks"] is False  # one rank with other weights is seen by every rank
+        out, mine = D.sample_sharded(_tiny_sampler(blob), seeds, gather=True)
+        assert mine == D.shard_seeds(seeds, rank, world)
+        if rank == 0:
+            torch.save(out, out_path)
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("seeds", [list(range(16)), list(range(100, 113)), [3, 1, 4]])  # even (2 per rank) / uneven (13 over 8) / ranks 3..7 empty
+def test_eight_ranks_match_single_process(tmp_path, seeds):
+    """the sharding layer at the world size of BASELINE configs[3] / configs[4] (8 ranks, gloo on CPU): contiguous
+    seed shards incl. uneven and EMPTY ones, one broadcast, a gather in seed order -- equal to one process sampling all seeds; and the
+    checksum all-reduce bench.py's `rccl` field reports (equal blobs: True on every rank; one deviating rank: False on every rank)."""
+    blob = torch.randn(1024, generator=torch.Generator().manual_seed(42)).view(torch.uint8).clone()
+    # (the stand-in denoiser is a CPU library convolution whose algorithm -- and last bits -- depend on the batch it is called with;
+    # what this test pins is the sharding layer: every shard sampled as one process would sample that shard, gathered in seed order)
+    from r2dm_amd.distributed import shard_seeds
+
+    want = torch.cat([_tiny_sampler(blob)(sh) for sh in (shard_seeds(seeds, r, 8) for r in range(8)) if sh])
+    assert torch.allclose(want, _tiny_sampler(blob)(seeds), atol=1e-5)
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(_worker8, args=(8, _free_port(), seeds, out_path), nprocs=8, join=True)
+    got = torch.load(out_path)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 def test_broadcast_packed_weights_single_process_is_a_noop_pack():
     """Without an initialised process group the helper only packs locally (needs the GPU -> here just the error)."""
     import r2dm_amd

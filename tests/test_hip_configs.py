@@ -202,8 +202,9 @@ def test_adopted_weight_blob_reproduces_the_packing_model():
     assert torch.equal(b.model(x, cond), ya)
     fresh, _, _ = r2dm_amd.setup_model(ck_b, device="cpu", show_info=False)  # a rank that never packed anything
     fresh.to(DEV)
-    fresh.model.adopt_packed_weights(blob)
+    fresh.model.adopt_packed_weights(blob, layout_hash=a.model.packed_layout_hash())
     assert torch.equal(fresh.model(x, cond), ya)
+    # (a blob planned for another batch size is refused: tests/test_host.py::test_blob_layout_fingerprint)
 
 
 def _free_port():
@@ -212,7 +213,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
+@pytest.mark.parametrize("cfg,batch", [(1, 2), (4, 1)])  # BASELINE configs[1] / configs[3] geometry, and configs[4]'s 128x2048
+def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path, cfg, batch):
     """bench.py under torch.distributed.run with two ranks sharing this GPU (gloo instead of RCCL): rank 0 packs, the blob
     is broadcast, rank 1 adopts it; every rank samples its own seed shard.  Each rank's samples equal those of a
     single-process run of the same seeds (sample_and_save.py:37-46,75: partition invariance).
@@ -222,21 +224,24 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     DESIGN.md section 6): the failure belonged to the old LDS-tiled out_conv kernel, disappeared with the commit that replaced it
     (1c7a0dc) and does not occur with any kernel of the current library -- 0 of 700 forwards at batch 2 / 8, both operand splits."""
     env = dict(os.environ, R2DM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-torch-baseline", "--no-exact-baseline", "--no-other-configs", "--prewarm-s", "0.5"]
+    common = ["--config", str(cfg), "--steps", "2", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline", "--no-torch-baseline", "--no-exact-baseline", "--no-other-configs",
+              "--prewarm-s", "0.5"]
     d2 = tmp_path / "two"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump-samples", str(d2)] + common,
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 * batch and line["scaling"] == "weak"
+    # the line proves the collective ran: backend, world size, and one all-reduce of the adopted blob's checksum (equal on all ranks)
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["backend"].startswith("gloo") and line["rccl"]["blob_crc_equal_on_all_ranks"] is True
     for rank in (0, 1):
         d1 = tmp_path / f"one{rank}"
-        r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--seed-base", str(2 * rank), "--dump-samples", str(d1)] + common,
+        r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--seed-base", str(batch * rank), "--dump-samples", str(d1)] + common,
                             env=env, capture_output=True, text=True, timeout=900)
         assert r1.returncode == 0, r1.stderr[-2000:]
         two, one = torch.load(d2 / f"rank{rank}.pt"), torch.load(d1 / "rank0.pt")
-        assert two["seeds"] == one["seeds"] == [2 * rank, 2 * rank + 1]
+        assert two["seeds"] == one["seeds"] == list(range(batch * rank, batch * rank + batch))
         assert torch.equal(two["samples"], one["samples"])
 
 

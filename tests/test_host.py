@@ -366,3 +366,20 @@ def test_replay_recovers_from_a_late_range_guard_trip_host_logic():
         run(Fake(1, strict=True), 100)
     x, _, rp = run(object(), 5) if False else (None, None, diffusion._Replay(object(), 5))
     assert rp.check is None and rp.due(0) is False and rp.due(4) is False  # any other denoiser: nothing to check, nothing kept
+
+
+def test_blob_layout_fingerprint():
+    """the f16x2 packing of a layer depends on the tile conv_f16x2_pick_co_tile chooses -- from max_batch, the CU
+    count, experiment switches -- and the byte count cannot tell two such layouts apart.  r2dm_blob_layout_hash fingerprints the plan;
+    a blob offered with another plan's fingerprint is refused before anything is bound (host-only: no GPU needed)."""
+    import r2dm_amd
+    from r2dm_amd._lib import R2DMError
+
+    ck = synthetic_ckpt()
+    m2, _, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=2)
+    m2b, _, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=2)
+    m8, _, _ = r2dm_amd.setup_model(ck, device="cpu", show_info=False, max_batch=8)
+    h2, h8 = m2.model.packed_layout_hash(), m8.model.packed_layout_hash()
+    assert h2 == m2b.model.packed_layout_hash() and h2 != h8 and h2 != 0
+    with pytest.raises(R2DMError, match="layout"):
+        m8.model.adopt_packed_weights(torch.empty(m8.model.packed_weight_bytes(), dtype=torch.uint8), layout_hash=h2)

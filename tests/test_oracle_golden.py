@@ -144,3 +144,22 @@ def test_lidar(golden):
     y = O.lidar_postprocess(g["x"], g["ray_angles"])
     assert max_abs(y, g["y"]) < 1e-4
     assert torch.allclose(O.hdl64e_ray_angles(*GOLDEN_RES), g["ray_angles"], atol=1e-7)
+
+
+def test_second_resolution_32x256(golden):
+    """Round 5: the oracle against the reference's own run at a second resolution (tests/golden/make_golden.py res2) -- whole denoiser,
+    a 4-step DDPM sample on the recorded noise, and FIR resamplers on maps whose width is a multiple of 4."""
+    g = golden("res32x256")
+    res = (32, 256)
+    sd2 = O.strip_prefix(synthetic_ckpt(resolution=res)["ema_weights"])
+    cfg2 = O.UNetConfig(resolution=res)
+    for i, c in enumerate(g["conds"].tolist()):
+        assert max_abs(O.unet_forward(sd2, cfg2, g["x"], torch.full((2,), c)), g["y"][i]) < 2e-5
+    net = lambda x, c: O.unet_forward(sd2, cfg2, x, c)
+    out = O.sample_continuous(net, (2, 2, *res), 4, noises=list(g["sample_noise"]), mode="ddpm")
+    # (4 coarse steps of an untrained, high-gain network: the handful of pixels that escape the clamp at t ~ 1 carry an amplified copy of
+    # the 1e-6 difference between two fp32 evaluations -- tests/test_hip_unet.py::test_sample_golden; rms and a loose maximum are the statement)
+    assert (out.double() - g["sample_out"].double()).pow(2).mean().sqrt().item() < 1e-5 and max_abs(out, g["sample_out"]) < 2e-3
+    for sfx in ("", "w"):
+        assert max_abs(O.fir_down2(g["down_x" + sfx]), g["down_y" + sfx]) < 1e-6
+        assert max_abs(O.fir_up2(g["up_x" + sfx]), g["up_y" + sfx]) < 1e-6

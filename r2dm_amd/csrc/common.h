@@ -106,6 +106,7 @@ struct ConvParams {
     const float* gn_ada = nullptr;       // [B][gn_ada_stride] rows = [scale(Cin) | shift(Cin)] (AdaGN) / nullptr
     long gn_ada_stride = 0;
     int* gn_range = nullptr;             // the engine's range flag (the bound gn_finalize would have recorded) / nullptr
+    int stagger = 0;  // experiment (R2DM_F2_STAGGER, conv_f16x2.hip): every other block of an XCD starts so many clock ticks late -- de-phases the blocks' tile ends
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };
 int conv_pick_algo(int Cin, int Cout, int taps);  // env R2DM_CONV_ALGO=f32 forces ALGO_F32 everywhere

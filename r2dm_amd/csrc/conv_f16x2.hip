@@ -155,6 +155,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     const int nIt = (total_tiles - (int)blockIdx.x + G - 1) / G;  // tiles of this block (grid <= total_tiles)
     const int Q = nIt * nchunks;
     const int c0 = p.x.c0;
+    if (p.stagger > 0 && nIt >= 3 && ((blockIdx.x >> 3) & 1)) {  // (experiment: half of the blocks out of phase with the other half)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+    }
 
     // tile `it` of this block -> output channel tile, sample, tile row / column (all wave-uniform: scalar ALU, F2Div)
     auto udiv = [&](unsigned x, int d, unsigned m) __attribute__((always_inline)) { return d == 1 ? x : __umulhi(x, m); };
@@ -1648,7 +1652,10 @@ bool conv_f16x2_fold_supported(const ConvParams& p, int groups, int slots) {
     return true;
 }
 
-hipError_t launch_conv_f16x2(const ConvParams& p, hipStream_t s) {
+hipError_t launch_conv_f16x2(const ConvParams& p_in, hipStream_t s) {
+    ConvParams p = p_in;
+    static const int stagger = getenv("R2DM_F2_STAGGER") ? atoi(getenv("R2DM_F2_STAGGER")) : 0;
+    p.stagger = stagger;
     if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile, p.px_rows)) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr && p.gn_partial == nullptr) return hipErrorInvalidValue;

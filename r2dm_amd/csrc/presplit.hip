@@ -2,7 +2,7 @@
 //
 // conv_f16x2's staging waves transform every input pixel of a tile -- silu(x a + d), then v = h + 2^-11 l -- once per 64-channel
 // OUTPUT tile: eight times for a 512-channel layer (/root/reference/models/efficient_unet.py:72-83,95-110: GroupNorm / AdaGN ->
-// SiLU -> ops.Conv2d), and that work, not the matrix pipe, bounds a chunk (in-kernel timelines).  For the
+// SiLU -> ops.Conv2d), and that work, not the matrix pipe, bounds a chunk (in-kernel timelines, LABNOTES.md section 5).  For the
 // coarse levels the tensor is small (8-34 MB at batch 8): this kernel applies the transform once, in the staging waves' own
 // arithmetic (bit-identical products), and writes the two fp16 planes in the order conv_f16x2's LDS x tile wants them, so that the
 // convolution's stagers only issue LDS-DMA:

@@ -221,7 +221,7 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path, cfg, batch):
 
     All runs use the DEFAULT kernels.  Round 2 ran this test with R2DM_CONV_ALGO=f32 because forwards next to a second process came
     out wrong (96 of 150) and blamed the LDS-DMA kernels; round 3 bisected it (scripts/jobs/j74-j77.sh, profiles/r03_shared_gpu.txt,
-    DESIGN.md section 6): the failure belonged to the old LDS-tiled out_conv kernel, disappeared with the commit that replaced it
+    LABNOTES.md section 6): the failure belonged to the old LDS-tiled out_conv kernel, disappeared with the commit that replaced it
     (1c7a0dc) and does not occur with any kernel of the current library -- 0 of 700 forwards at batch 2 / 8, both operand splits."""
     env = dict(os.environ, R2DM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--config", str(cfg), "--steps", "2", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline", "--no-torch-baseline", "--no-exact-baseline", "--no-other-configs",

@@ -62,8 +62,8 @@ constexpr int ADTAB_BYTES = 4096;                           // (a, d) of the cur
 //                (2, 4): 64 channels x 8 rows, ONE accumulator (round 5, the "tall" tile: what the 128-channel tile is to layers with
 //                        >= 128 output channels, for the layers with 64: 24 MFMAs per tap between two barriers, a halo of 10 / 8 instead
 //                        of 6 / 4 rows, one tile end per 512 pixels)
-//                (2, 1): 64 channels x 2 rows, two accumulators (round 5, the "short" tile: twice the tiles where a launch has fewer
-//                        tiles than the chip has CUs)
+//                (1, 2): 32 channels x 4 rows, two accumulators (round 5: twice the tiles where a launch has fewer 64-channel tiles than the chip
+//                        has CUs -- u_block4 ran on 128 of 256 CUs; same x tile and stagers, half the MFMAs per chunk: stager-bound)
 template <int MRK, int NRK>
 struct Geo {
     static constexpr int COT = 32 * MRK;                        // output channels per tile
@@ -105,7 +105,7 @@ template <int PRO, int NPLK, int MRK, int NRK>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
     static_assert(NPLK == 1 || NPLK == 2, "planes");
-    static_assert((MRK == 2 && (NRK == 2 || NRK == 4)) || (MRK == 4 && NRK == 2), "tile family");
+    static_assert((MRK == 2 && (NRK == 2 || NRK == 4)) || (MRK == 4 && NRK == 2) || (MRK == 1 && NRK == 2 && NPLK == 2), "tile family");
     using GEO = Geo<MRK, NRK>;
     // (the tile's own geometry shadows x3's constants of the same names)
     constexpr int MR = MRK, NR = NRK, TH = GEO::TH, XR = GEO::XR, XPL = GEO::XPL, XBYTES = GEO::XBYTES, NQ = GEO::NQ, NU = GEO::NU;
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     // plane is the first 6 pieces of a stage: stager w fetches pieces w and w + 2 (pieces 2 and 3 twice: harmless).
     // MRK == 4 -- NPLK == 2: 24 pieces per stage, six per stager; NPLK == 1: the h plane = 12 pieces, three per stager
     // MFMAs per tap: 3 MR NR with both planes (6 | 12 | 24), MR NR with one
-    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = MRK == 2 ? (NPLK == 2 ? 3 : 2) : (NPLK == 2 ? 6 : 3);
+    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = MRK == 1 ? 2 : MRK == 2 ? (NPLK == 2 ? 3 : 2) : (NPLK == 2 ? 6 : 3);
+    // (MRK == 1: a stage is 6 pieces -- both planes of 32 channels --, fetched like the h plane of the 64-channel tile: pieces w and w + 2)
     // A weight stage must have landed when the barrier in front of its first read is reached; so many younger operations of the
     // stager may still be in flight then (vmcnt retires in order; the queue holds loads only).  Per iteration the queue is
     //   D0 [PPW] | #1 | D1 [PPW] | #2 | D2 [PPW], raw [NL] | #3        NL = 8 global loads per staging unit of the iteration
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             // address their own entry (tile row outside the image: the layout's zero rows; azimuth wrap: a lane address).  No pixel
             // loads, no transform, no LDS writes: ~16 DMA instructions per chunk and wave.  Queue of one iteration:
             //   D0 [PPW], x(q+1) [PPX] | #1 | D1 [PPW] | #2 | D2 [PPW] | #3        (x(q+1) has three segments to land)
-            static_assert(MRK == 2 && RING == 4, "pre-split input: 64-channel tiles");
+            static_assert(MRK <= 2 && NRK == 2 && RING == 4, "pre-split input: 64 x 4 and 32 x 4 tiles");
             constexpr int NENT = NPLK * XPL, NPIECE = (NENT + 63) / 64, PPX = (NPIECE + 3) / 4;
             const int plane_px = (H + 2) * W;  // 16-byte entries per (plane, group)
             const unsigned chunk_bytes = (unsigned)(NPL * NG * plane_px) * 16u;
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         for (int i = 0; i < UNITS; ++i) {
             const int qq = NPLK == 2 ? i / (MR * NR) : 2, m = (i / NR) % MR, n = i % NR;  // (one plane: the xh wh product only)
             if (i == MR * NR) {
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MR + NR) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NOPS < MR * NR ? NOPS : MR * NR) : "memory");  // (the reads this tap has issued so far are younger)
                 __builtin_amdgcn_sched_barrier(0);
             }
             f32x16& ac = !ACC2 || qq == 2 ? acc[m][n] : acl[ACC2 ? m : 0][ACC2 ? n : 0];
@@ -975,7 +976,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (i == 0) fr(ic<0>{}, ic<0>{});
             if (i == 1) fr(ic<0>{}, ic<1>{});
             if (i == 2) fr(ic<0>{}, ic<2>{});
-            if (i == 3) fr(ic<0>{}, ic<3>{});
+            if constexpr (NOPS >= 4) {
+                if (i == 3) fr(ic<0>{}, ic<3>{});
+            }
+            if constexpr (NPLK == 2 && MR == 1) {  // (units: 0, 1 xh wl | 2, 3 xl wh | 4, 5 xh wh)
+                if (i == 2) fr(ic<1>{}, ic<0>{});  // wl' (its last product was unit 1)
+                if (i == 4) fr(ic<1>{}, ic<1>{});  // xl' (its last product was unit 3)
+                if (i == 5) fr(ic<1>{}, ic<2>{});
+            }
             if constexpr (NOPS == 6) {
                 if (i == 4) fr(ic<0>{}, ic<4>{});
                 if (i == 5) fr(ic<0>{}, ic<5>{});
@@ -1018,7 +1026,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
     using gf4 = f32x4 __attribute__((address_space(1)))*;
     constexpr int SEGW = TW / 32;
-    static_assert(ONEACC || (NQ == 4 && RESQ == 3), "three deferred quarters in the former residual area");
+    static_assert(ONEACC || ((NQ == 4 || NQ == 2) && RESQ == NQ - 1), "all quarters but the first wait in LDS");
     float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
     f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
     float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
@@ -1118,14 +1126,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         for (int k8 = 0; k8 < 4; ++k8) t[k8] = *reinterpret_cast<const f32x4*>(dump + (S - 1) * 1024 + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
         float ps[4], pq[4];
         quarter(SS, t, rv, pe_b, pe_th, pe_tw, pe_cot, ln, ps, pq);
-        if (S < 3 && decltype(NEXT)::value) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
+        if constexpr (S < NQ - 1 && decltype(NEXT)::value) res_request(ic<S + 1>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
         if (S == 1) half_stats(ic<0>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
         if (S == 2) {
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) { cs[k8] = ps[k8]; cq[k8] = pq[k8]; }
         }
-        if (S == 3) {
-            half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
+        if (S == 3) half_stats(ic<1>{}, cs, cq, ps, pq, pe_b, pe_th, pe_tw, pe_cot, ln);
+        if (S == NQ - 1) {  // the tile's last quarter
             range_flush(ln);
             pending = false;
         }
@@ -1382,9 +1390,13 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         } else {
         if constexpr (decltype(PAR)::value == 0) {
             if (pending && e_c == 1) slice(ic<1>{});
-            if (pending && e_c == 3) slice(ic<3>{});
+            if constexpr (NQ == 4) {
+                if (pending && e_c == 3) slice(ic<3>{});
+            }
         } else {
-            if (pending && e_c == 2) slice(ic<2>{});
+            if constexpr (NQ == 4) {
+                if (pending && e_c == 2) slice(ic<2>{});
+            }
             if (e_c == nchunks) {  // tile finished
                 e_c = 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read may land in a register the epilogue reuses
@@ -1402,9 +1414,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 // the registers the second accumulator has just left, and the quarters follow right below)
                 const bool last_tile = e_item + 1 == nIt;
                 f32x4 rv2[4] = {}, rv3[4] = {};
-                if (last_tile) {
-                    res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
-                    res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                if constexpr (NQ == 4) {
+                    if (last_tile) {
+                        res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
+                        res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                    }
                 }
                 // quarter 0 right away (through the 1 KiB patch, block by block), quarters 1..3 into the LDS area
                 {
@@ -1417,8 +1431,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         t[k8] = *reinterpret_cast<const f32x4*>(patch + (ln >> 3) * 32 + (ln & 7) * 4);
                     }
                     turn_write(ic<1>{}, dump, ln);
-                    turn_write(ic<2>{}, dump + 1024, ln);
-                    turn_write(ic<3>{}, dump + 2048, ln);
+                    if constexpr (NQ == 4) {
+                        turn_write(ic<2>{}, dump + 1024, ln);
+                        turn_write(ic<3>{}, dump + 2048, ln);
+                    }
                     quarter(ic<0>{}, t, rv_e, e_b, e_th, e_tw, e_cot, ln, cs, cq);
                     res_request(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
                 }
@@ -1428,16 +1444,22 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 if (last_tile) {
                     slice_rv(ic<1>{}, rv_e, ic<0>{});
                     stamp(41);
-                    slice_rv(ic<2>{}, rv2, ic<0>{});
-                    stamp(42);
-                    slice_rv(ic<3>{}, rv3, ic<0>{});  // (clears `pending`)
-                    stamp(43);
+                    if constexpr (NQ == 4) {
+                        slice_rv(ic<2>{}, rv2, ic<0>{});
+                        stamp(42);
+                        slice_rv(ic<3>{}, rv3, ic<0>{});  // (clears `pending`)
+                        stamp(43);
+                    }
                 }
                 // both accumulators restart from C = 0 in the next tile's first products; the compiler cannot see that the
                 // "accumulate" branch is never taken there and would keep all 128 registers alive: an empty definition ends
                 // the old values' lives (no instruction)
-                asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
-                if constexpr (NPLK == 2) asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
+                if constexpr (MR == 2) {
+                    asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
+                    if constexpr (NPLK == 2) asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
+                } else {
+                    asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acl[0][0]), "=v"(acl[0][1]));
+                }
                 if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
                 // first fragments of the next tile (its chunk 0 sits in x buffer 0, stage 3(q+1) in the ring: published at
                 // this chunk's last barrier); also after the last tile -- harmless, keeps the registers plainly defined
@@ -1515,9 +1537,9 @@ static int f2_cu_count() {
 
 // 3x3, whole px_rows x 64 pixel tiles (the wide epilogue has no pixel predication), 64- (or 128-) channel output tiles, 64 <= Cin <= 512 in
 // multiples of 64 (an even number of 16-channel chunks, at least four; the (a, d) table), a concat seam on a chunk boundary.
-// Tiles (co_tile x px_rows): 64 x 4 (two accumulators), 128 x 4 and 64 x 8 (one).
+// Tiles (co_tile x px_rows): 64 x 4 and 32 x 4 (two accumulators), 128 x 4 and 64 x 8 (one).
 bool conv_f16x2_supported(int Cin, int Cout, int taps, int H, int W, int co_tile, int px_rows) {
-    const bool tile_ok = (co_tile == 64 && (px_rows == 4 || px_rows == 8)) || (co_tile == 128 && px_rows == 4);
+    const bool tile_ok = (co_tile == 64 && (px_rows == 4 || px_rows == 8)) || ((co_tile == 128 || co_tile == 32) && px_rows == 4);
     return taps == 9 && tile_ok && Cout % co_tile == 0 && Cin % (4 * f2::CK) == 0 && Cin * 8 <= f2::ADTAB_BYTES &&
            H % px_rows == 0 && W % f2::TW == 0 && H * (long)W * 16 < (1L << 31);
 }
@@ -1529,8 +1551,10 @@ int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_b
     int rows_dummy;
     int& rows = px_rows ? *px_rows : rows_dummy;
     rows = 4;
-    if (const char* e = getenv("R2DM_F2_CO_TILE")) {  // "64" | "128" | "64x8" (read per call: per-kernel tests switch it)
+    const bool narrow_ok = conv_f16x2_supported(Cin, Cout, 9, H, W, 32, 4);
+    if (const char* e = getenv("R2DM_F2_CO_TILE")) {  // "32" | "64" | "128" | "64x8" (read per call: per-kernel tests switch it)
         if (atoi(e) == 128 && wide_ok) return 128;
+        if (atoi(e) == 32 && narrow_ok) return 32;
         if (strstr(e, "x8") && tall_ok && px_rows) rows = 8;
         return 64;
     }
@@ -1545,6 +1569,9 @@ int conv_f16x2_pick_co_tile(int Cin, int Cout, int H, int W, long pixels_times_b
     if (wide_ok && Cin <= max_cin && px_tiles * (Cout / 128) >= f2_cu_count()) return 128;
     // (the eight-row tile pays where a block has enough chunks to amortise its longer tile end: measured per launch at batch 8, profiles/r05_tall_tile.txt --
     // level-1 64 -> 64 -5 %, 128 -> 64 -6 %, 256 -> 64 @ 32 x 512 -4 %; 64 -> 64 @ 32 x 512, two four-chunk tiles per block, +3 %: left on the 64 x 4 tile)
+    // fewer 64-channel tiles than CUs (u_block4 at batch 8: 128): 32-channel tiles, so that every CU has one (R2DM_F2_NARROW=0: never)
+    static const bool narrow_on = !getenv("R2DM_F2_NARROW") || atoi(getenv("R2DM_F2_NARROW")) != 0;
+    if (narrow_ok && narrow_on && px_tiles * (Cout / 64) < f2_cu_count() && px_tiles * (Cout / 32) >= px_tiles * (Cout / 64) * 2) return 32;
     if (tall_ok && tall_on && px_rows && Cin <= max_cin && (px_tiles / 2) * (Cout / 64) * (long)(Cin / f2::CK) >= 16L * f2_cu_count()) rows = 8;
     return 64;
 }
@@ -1572,14 +1599,14 @@ hipError_t launch_weight_absmax(const float* w, long n, int* max_bits, hipStream
 }
 
 hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale, int co_tile, int px_rows) {
-    if ((co_tile != 64 && co_tile != 128) || Cout % co_tile || (px_rows != 4 && !(px_rows == 8 && co_tile == 64))) return hipErrorInvalidValue;
+    if ((co_tile != 32 && co_tile != 64 && co_tile != 128) || Cout % co_tile || (px_rows != 4 && !(px_rows == 8 && co_tile == 64))) return hipErrorInvalidValue;
     const long total = (long)Cout * Cin * 9 * f2::NPL;
     if (wscale) {
         hipError_t e = launch_weight_absmax(w, (long)Cout * Cin * 9, reinterpret_cast<int*>(wscale), s);
         if (e != hipSuccess) return e;
     }
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale, co_tile, co_tile == 64 && px_rows == 4);  // (the one-accumulator tiles: l planes at their true scale)
+    pack_conv_f16x2_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(dst), Cout, Cin, total, range_flag, wscale, co_tile, co_tile <= 64 && px_rows == 4);  // (the one-accumulator tiles: l planes at their true scale)
     return hipGetLastError();
 }
 
@@ -1609,9 +1636,18 @@ template <int MRK, int NRK>
 static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
     using GEO = f2::Geo<MRK, NRK>;
     const long tiles = (long)(p.Cout / GEO::COT) * (p.W / f2::TW) * (p.H / GEO::TH) * p.B;
-    if constexpr (MRK == 2 && NRK == 2) {  // pre-split input (presplit.hip): 64 x 4 tiles only
+    if constexpr (MRK == 2 && NRK == 2) {  // pre-split input (presplit.hip): 64 x 4 tiles (and 32 x 4 below)
         if (p.prologue == PRO_PRESPLIT) return p.pieces == 1 ? launch_f2<PRO_PRESPLIT, 1, 2, 2>(p, tiles, s) : launch_f2<PRO_PRESPLIT, 2, 2, 2>(p, tiles, s);
     }
+    if constexpr (MRK == 1) {  // (the split arithmetic only: the one-plane mode keeps the 64-channel tile)
+        switch (p.prologue) {
+            case PRO_NONE: return launch_f2<PRO_NONE, 2, 1, 2>(p, tiles, s);
+            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2, 1, 2>(p, tiles, s);
+            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2, 1, 2>(p, tiles, s);
+            case PRO_PRESPLIT: return launch_f2<PRO_PRESPLIT, 2, 1, 2>(p, tiles, s);
+        }
+        return hipErrorInvalidValue;
+    } else {
     if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
         switch (p.prologue) {
             case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK, NRK>(p, tiles, s);
@@ -1625,6 +1661,7 @@ static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
         case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2, MRK, NRK>(p, tiles, s);
     }
     return hipErrorInvalidValue;
+    }
 }
 
 // GroupNorm folded into this launch?  8 groups of 8 .. 64 channels over exactly the input channels, at most 4 x 256 statistics slots per
@@ -1660,11 +1697,12 @@ hipError_t launch_conv_f16x2(const ConvParams& p_in, hipStream_t s) {
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr && p.gn_partial == nullptr) return hipErrorInvalidValue;
     if (p.gn_partial && (p.aff != nullptr || p.gn_cpg * 8 != p.Cin || !conv_f16x2_fold_supported(p, 8, p.gn_slots))) return hipErrorInvalidValue;
-    if (p.prologue == PRO_PRESPLIT && (p.co_tile != 64 || p.px_rows != 4 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
+    if (p.prologue == PRO_PRESPLIT && ((p.co_tile != 64 && p.co_tile != 32) || p.px_rows != 4 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
+    if (p.co_tile == 32 && p.pieces == 1) return hipErrorInvalidValue;  // (32-channel tiles exist in the split arithmetic only)
 #ifndef F2_PROF
     if (p.prof != nullptr) return hipErrorInvalidValue;
 #endif
-    return p.co_tile == 128 ? launch_f2_tile<4, 2>(p, s) : p.px_rows == 8 ? launch_f2_tile<2, 4>(p, s) : launch_f2_tile<2, 2>(p, s);
+    return p.co_tile == 128 ? launch_f2_tile<4, 2>(p, s) : p.co_tile == 32 ? launch_f2_tile<1, 2>(p, s) : p.px_rows == 8 ? launch_f2_tile<2, 4>(p, s) : launch_f2_tile<2, 2>(p, s);
 }
 
 }  // namespace r2dm

@@ -104,7 +104,8 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
     ref = (res.double() + O.conv_ring(xa, wt.double(), b.double())) * 0.70710678
     out = {}
     variants = ([("f16x2/64", 2, "64"), ("bf16x3", 3, None), ("f32 mfma", 4, None), ("f32 chain", 5, None)] + ([("f16x2/128", 2, "128")] if cout % 128 == 0 else [])
-                + ([("f16x2/64x8", 2, "64x8")] if h % 8 == 0 else []))  # (round 5: the one-accumulator tile of 64 channels x 8 rows)
+                + ([("f16x2/64x8", 2, "64x8")] if h % 8 == 0 else [])  # (round 5: the one-accumulator tile of 64 channels x 8 rows)
+                + [("f16x2/32", 2, "32")])                              # (round 5: 32-channel tiles for launches with fewer 64-channel tiles than CUs)
     saved = os.environ.get("R2DM_F2_CO_TILE")
     for name, pieces, tile in variants:
         H.set_conv_pieces(pieces)
@@ -132,6 +133,7 @@ def test_conv3x3_both_operand_splits(O, H, cin, cout, h, w, pro):
         assert not torch.equal(out["f32 mfma"], out["f32 chain"]) and e["f32 mfma"][1] < e["f32 chain"][1]  # (the hook took effect; two levels pay)
     if "f16x2/128" in e:
         assert not torch.equal(out["f16x2/64"], out["f16x2/128"])  # (the 128-channel tile really ran)
+    assert torch.equal(out["f16x2/32"], out["f16x2/64"])  # (two accumulators, the same products in the same order per output element)
     if "f16x2/64x8" in e:
         assert not torch.equal(out["f16x2/64"], out["f16x2/64x8"])  # (the eight-row tile really ran)
         if "f16x2/128" in e:  # both one-accumulator tiles do the same arithmetic per output element, in the same order

@@ -105,7 +105,7 @@ template <int PRO, int NPLK, int MRK, int NRK>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
     static_assert(NPLK == 1 || NPLK == 2, "planes");
-    static_assert((MRK == 2 && (NRK == 2 || NRK == 4)) || (MRK == 4 && NRK == 2) || (MRK == 1 && NRK == 2 && NPLK == 2), "tile family");
+    static_assert((MRK == 2 && (NRK == 2 || NRK == 4)) || (MRK == 4 && NRK == 2) || (MRK == 1 && NRK == 2), "tile family");
     using GEO = Geo<MRK, NRK>;
     // (the tile's own geometry shadows x3's constants of the same names)
     constexpr int MR = MRK, NR = NRK, TH = GEO::TH, XR = GEO::XR, XPL = GEO::XPL, XBYTES = GEO::XBYTES, NQ = GEO::NQ, NU = GEO::NU;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     // plane is the first 6 pieces of a stage: stager w fetches pieces w and w + 2 (pieces 2 and 3 twice: harmless).
     // MRK == 4 -- NPLK == 2: 24 pieces per stage, six per stager; NPLK == 1: the h plane = 12 pieces, three per stager
     // MFMAs per tap: 3 MR NR with both planes (6 | 12 | 24), MR NR with one
-    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = MRK == 1 ? 2 : MRK == 2 ? (NPLK == 2 ? 3 : 2) : (NPLK == 2 ? 6 : 3);
+    constexpr int UNITS = (NPLK == 2 ? 3 : 1) * MR * NR, PPW = MRK == 1 ? (NPLK == 2 ? 2 : 1) : MRK == 2 ? (NPLK == 2 ? 3 : 2) : (NPLK == 2 ? 6 : 3);
     // (MRK == 1: a stage is 6 pieces -- both planes of 32 channels --, fetched like the h plane of the 64-channel tile: pieces w and w + 2)
     // A weight stage must have landed when the barrier in front of its first read is reached; so many younger operations of the
     // stager may still be in flight then (vmcnt retires in order; the queue holds loads only).  Per iteration the queue is
@@ -255,7 +255,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                              :
                              : "v"(l16), "s"(s3 + 4096), "s"(d3 + 4096u)
                              : "memory", "m0");
-            } else {  // 64-channel tiles, the h plane only (6 KiB at the start of the stage): pieces w and w + 2
+            } else if constexpr (PPW == 1) {  // 32-channel tiles, the h plane only (3 KiB): piece w (stager 3: piece 2 again -- harmless, uniform bookkeeping)
+                const int pc = wv < 3 ? wv : 2;
+                const unsigned char* s3 = src + pc * 1024;
+                const unsigned d3 = l0 + WB0 + (unsigned)(slot * WSTAGE + pc * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %1"
+                             :
+                             : "v"(l16), "s"(s3), "s"(d3)
+                             : "memory", "m0");
+            } else {  // 64-channel tiles, the h plane only (6 KiB at the start of the stage): pieces w and w + 2; 32-channel tiles, both planes (6 KiB)
                 const unsigned char* s3 = src + wv * 1024;
                 const unsigned d3 = l0 + WB0 + (unsigned)(slot * WSTAGE + wv * 1024);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
@@ -976,6 +985,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             if (i == 0) fr(ic<0>{}, ic<0>{});
             if (i == 1) fr(ic<0>{}, ic<1>{});
             if (i == 2) fr(ic<0>{}, ic<2>{});
+            if constexpr (NPLK == 1 && UNITS == 2) {  // (32-channel tile, one plane: two MFMAs per tap carry three reads)
+                if (i == 1) fr(ic<0>{}, ic<2>{});
+            }
             if constexpr (NOPS >= 4) {
                 if (i == 3) fr(ic<0>{}, ic<3>{});
             }
@@ -1639,15 +1651,10 @@ static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
     if constexpr (MRK == 2 && NRK == 2) {  // pre-split input (presplit.hip): 64 x 4 tiles (and 32 x 4 below)
         if (p.prologue == PRO_PRESPLIT) return p.pieces == 1 ? launch_f2<PRO_PRESPLIT, 1, 2, 2>(p, tiles, s) : launch_f2<PRO_PRESPLIT, 2, 2, 2>(p, tiles, s);
     }
-    if constexpr (MRK == 1) {  // (the split arithmetic only: the one-plane mode keeps the 64-channel tile)
-        switch (p.prologue) {
-            case PRO_NONE: return launch_f2<PRO_NONE, 2, 1, 2>(p, tiles, s);
-            case PRO_AFFINE: return launch_f2<PRO_AFFINE, 2, 1, 2>(p, tiles, s);
-            case PRO_AFFINE_SILU: return launch_f2<PRO_AFFINE_SILU, 2, 1, 2>(p, tiles, s);
-            case PRO_PRESPLIT: return launch_f2<PRO_PRESPLIT, 2, 1, 2>(p, tiles, s);
-        }
-        return hipErrorInvalidValue;
-    } else {
+    if constexpr (MRK == 1) {
+        if (p.prologue == PRO_PRESPLIT) return p.pieces == 1 ? hipErrorInvalidValue : launch_f2<PRO_PRESPLIT, 2, 1, 2>(p, tiles, s);
+    }
+    {
     if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
         switch (p.prologue) {
             case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK, NRK>(p, tiles, s);
@@ -1698,7 +1705,6 @@ hipError_t launch_conv_f16x2(const ConvParams& p_in, hipStream_t s) {
     if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr && p.gn_partial == nullptr) return hipErrorInvalidValue;
     if (p.gn_partial && (p.aff != nullptr || p.gn_cpg * 8 != p.Cin || !conv_f16x2_fold_supported(p, 8, p.gn_slots))) return hipErrorInvalidValue;
     if (p.prologue == PRO_PRESPLIT && ((p.co_tile != 64 && p.co_tile != 32) || p.px_rows != 4 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
-    if (p.co_tile == 32 && p.pieces == 1) return hipErrorInvalidValue;  // (32-channel tiles exist in the split arithmetic only)
 #ifndef F2_PROF
     if (p.prof != nullptr) return hipErrorInvalidValue;
 #endif

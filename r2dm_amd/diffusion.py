@@ -264,6 +264,11 @@ class GaussianDiffusion(nn.Module):
         denoiser's stream instead of following it.  Same draws in the same order as base.py:71-94 (the denoiser draws nothing;
         a generator's state advances on the host at launch time); the caller waits for ``event`` before it reads ``noise``.
         ``R2DM_NOISE_STREAM=0`` or a CPU tensor: a plain ``randn_like`` and no event."""
+        if os.environ.get("R2DM_DEBUG_FIXED_NOISE") == "1":  # timing experiment only (WRONG samples): what do the step's noise launches cost?
+            z = self.__dict__.get("_fixed_noise")
+            if z is None or z.shape != x.shape or z.device != x.device:
+                z = self.__dict__["_fixed_noise"] = self.randn_like(x, rng=rng)
+            return z, None
         if x.device.type != "cuda" or os.environ.get("R2DM_NOISE_STREAM", "1") == "0":
             return self.randn_like(x, rng=rng), None
         side = self.__dict__.get("_noise_stream")

@@ -65,6 +65,32 @@ def test_conv_one_product_is_exactly_fp16_operands(O, H, k, cin, cout, h, w):
     assert 3e-5 < e_truth < 6e-4    # ... and really the reduced mode (the parity mode sits at ~2e-7)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(256, 256, 8, 128), (128, 128, 16, 256)])
+def test_conv_one_product_tiles_are_bit_identical(H, cin, cout, h, w):
+    """Round 5: every tile of conv_f16x2 in the one-product mode -- 64 x 4, 128 x 4, 64 x 8 and the 32-channel tile u_block4 runs on at batch 8
+    (whose one-plane weight stage is three DMA pieces for four staging waves) -- computes one product per MAC into one accumulator in the same
+    order: bit-identical outputs, with GroupNorm + SiLU prologue, residual and scale."""
+    import os
+
+    x, wt, b = rnd(1, 3, cin, h, w), rnd(2, cout, cin, 3, 3) / math.sqrt(9 * cin), rnd(3, cout)
+    res = rnd(4, 3, cout, h, w)
+    aff = torch.stack([torch.rand(3, cin) + 0.5, torch.randn(3, cin) * 0.3], -1).contiguous()
+    outs = {}
+    saved = os.environ.get("R2DM_F2_CO_TILE")
+    H.set_conv_pieces(1)
+    try:
+        for tile in ("64", "32", "128", "64x8"):
+            os.environ["R2DM_F2_CO_TILE"] = tile
+            outs[tile] = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), aff=aff.to(DEV), prologue=2, residual=res.to(DEV), scale=0.70710678).cpu()
+    finally:
+        H.set_conv_pieces(2)
+        os.environ.pop("R2DM_F2_CO_TILE", None)
+        if saved is not None:
+            os.environ["R2DM_F2_CO_TILE"] = saved
+    for tile in ("32", "128", "64x8"):
+        assert torch.equal(outs[tile], outs["64"]), tile
+
+
 @pytest.mark.parametrize("pro", [1, 2])
 def test_conv_one_product_with_fused_prologue(O, H, pro):
     import torch.nn.functional as F

@@ -1626,7 +1626,14 @@ template <int PRO, int NPLK, int MRK, int NRK>
 static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
     auto kern = conv_f16x2_kernel<PRO, NPLK, MRK, NRK>;
     using GEO = f2::Geo<MRK, NRK>;
-    constexpr int LDS_TOTAL = GEO::LDS_TOTAL, COT = GEO::COT;
+    // The whole LDS of the CU, whatever the tile needs (the 32-channel tile: 98 KiB): a persistent block must not share its CU with a
+    // workgroup of ANOTHER process.  Next to a neighbour process whose workgroups hold LDS, the 32-channel tile -- the only tile that left
+    // room for them -- ended in a GPU memory fault (scripts/jobs/j314.sh .. j316.sh: not without the neighbour, not with R2DM_F2_NARROW=0);
+    // the same signature as round 2's "wrong results next to a second process" of a 17 KiB-LDS kernel (LABNOTES.md section 6): whatever the
+    // platform does there, a block that owns the CU's LDS is not exposed to it.  R2DM_F2_LDS_EXACT=1: experiments.
+    static const bool lds_exact = getenv("R2DM_F2_LDS_EXACT") != nullptr;
+    const int LDS_TOTAL = GEO::LDS_TOTAL >= 156 * 1024 || lds_exact ? GEO::LDS_TOTAL : 156 * 1024;
+    constexpr int COT = GEO::COT;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);

@@ -106,6 +106,9 @@ struct ConvParams {
     const float* gn_ada = nullptr;       // [B][gn_ada_stride] rows = [scale(Cin) | shift(Cin)] (AdaGN) / nullptr
     long gn_ada_stride = 0;
     int* gn_range = nullptr;             // the engine's range flag (the bound gn_finalize would have recorded) / nullptr
+    // fp16 STORAGE of activations (conv_f16x2.hip, the one-plane mode: round 5): x16 -- the input tensor(s) hold fp16; y16 -- the output and
+    // the residual do.  Pointers stay typed float*, batch strides stay in ELEMENTS.
+    int x16 = 0, y16 = 0;
     int stagger = 0;  // experiment (R2DM_F2_STAGGER, conv_f16x2.hip): every other block of an XCD starts so many clock ticks late -- de-phases the blocks' tile ends
     unsigned long long* prof = nullptr;  // optional [nblk][4] s_memtime stamps (perf probe; nullptr in production)
 };

@@ -101,10 +101,18 @@ static unsigned f2_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ull
 // 1 = the h plane alone, ONE fp16 product per MAC with fp32 accumulation -- the reduced-precision bulk mode that mirrors the
 // reference's fp16 autocast sampler (/root/reference/sample_and_save.py:70, utils/option.py:49): same packing, same tiles,
 // the l plane is neither fetched, computed nor multiplied.
-template <int PRO, int NPLK, int MRK, int NRK>
+// IOM (round 5, the one-plane mode only): activations stored as fp16 in HBM, as the reference's autocast stores its convolution outputs
+// (/root/reference/sample_and_save.py:45,70) -- bit 0: the input tensor is fp16, bit 1: the output and the residual are.  Everything in
+// between stays what it is: fp32 GroupNorm affine + SiLU on the way in, fp32 accumulation, fp32 bias / residual / scale, statistics of
+// the values as stored.
+template <int PRO, int NPLK, int MRK, int NRK, int IOM = 0>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, const int total_tiles, const F2Div dv) {
     using namespace f2;
     static_assert(NPLK == 1 || NPLK == 2, "planes");
+    static_assert(IOM == 0 || (NPLK == 1 && PRO != PRO_PRESPLIT), "fp16 storage: the one-plane mode");
+    constexpr bool X16 = (IOM & 1) != 0, Y16 = (IOM & 2) != 0;
+    constexpr int XE = X16 ? 2 : 4, YE = Y16 ? 2 : 4;  // bytes per stored element
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
     static_assert((MRK == 2 && (NRK == 2 || NRK == 4)) || (MRK == 4 && NRK == 2) || (MRK == 1 && NRK == 2), "tile family");
     using GEO = Geo<MRK, NRK>;
     // (the tile's own geometry shadows x3's constants of the same names)
@@ -404,8 +412,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 
         // ---- load cursor: the chunk whose pixels are fetched next (two to three chunks ahead of the multipliers) ----
         int l_item = 0, l_c = 0;
-        const float* l_x0 = nullptr;
-        const float* l_x1 = nullptr;
+        const unsigned char* l_x0 = nullptr;  // (byte pointers: the input is fp32 or, IOM bit 0, fp16)
+        const unsigned char* l_x1 = nullptr;
         unsigned l_voff[NU];  // this lane's byte offset inside a channel group's planes (per unit)
         bool l_ok[NU];
         bool l_edge = false;  // (wave-uniform) the tile touches the top or bottom image row: some lanes' rows are zero padding
@@ -419,15 +427,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 if (gc >= W) gc -= W;  // azimuth is periodic
                 const int gr = th * TH + s_row[u] - 1;
                 l_ok[u] = gr >= 0 && gr < H;  // rows outside [0,H) are zero padding (of the ACTIVATED tensor)
-                l_voff[u] = (unsigned)(s_g[u] * 8 * HW + (l_ok[u] ? gr * W + gc : 0)) * 4u;  // (16 HW floats < 2^31: launcher)
+                l_voff[u] = (unsigned)(s_g[u] * 8 * HW + (l_ok[u] ? gr * W + gc : 0)) * (unsigned)XE;  // (16 HW floats < 2^31: launcher)
             }
             l_edge = th == 0 || th == nTh - 1;
-            l_x0 = p.x.p0 + b * p.x.bs0;
-            l_x1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
+            l_x0 = reinterpret_cast<const unsigned char*>(p.x.p0) + (long)b * p.x.bs0 * XE;
+            l_x1 = p.x.p1 ? reinterpret_cast<const unsigned char*>(p.x.p1) + (long)b * p.x.bs1 * XE : reinterpret_cast<const unsigned char*>(p.x.p0);
         };
         // Two register sets of raw pixels: the set filled in iteration q is transformed in iteration q+2.
+        // four pixels of one channel: 16 bytes of fp32 or 8 of fp16 (one 64-bit scalar: as a vector of two dwords behind the inline-assembly
+        // load, hipcc read dword 0 for all four pixels)
+        using RAW = std::conditional_t<X16, unsigned long long, f32x4>;
         struct RawSet {
-            f32x4 raw[NU][8];  // per unit: 8 channels x 4 pixels
+            RAW raw[NU][8];    // per unit: 8 channels x 4 pixels
             bool ok[NU];       // row inside the image
             bool edge;         // wave-uniform: the tile has padding rows at all (interior tiles skip the masking)
         };
@@ -443,14 +454,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         auto gload = [&](f32x4& d, const unsigned char* base, unsigned voff) __attribute__((always_inline)) {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
         };
+        auto gload_px = [&](RAW& d, const unsigned char* base, unsigned voff) __attribute__((always_inline)) {
+            if constexpr (X16) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+        };
         // the cursor's chunk, units 0 .. NUR - 1: 8 loads each; advances the cursor
         auto load_next = [&](RawSet& r, auto NUR) __attribute__((always_inline)) {
             const int ci0 = l_c * CK;
-            const unsigned char* xq = sbase(ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW : l_x0 + (long)ci0 * HW);
+            const unsigned char* xq = sbase(ci0 >= c0 ? l_x1 + (long)(ci0 - c0) * HW * XE : l_x0 + (long)ci0 * HW * XE);
 #pragma unroll
             for (int u = 0; u < decltype(NUR)::value; ++u) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gload(r.raw[u][i], xq + (size_t)i * HW * 4, l_voff[u]);
+                for (int i = 0; i < 8; ++i) gload_px(r.raw[u][i], xq + (size_t)i * HW * XE, l_voff[u]);
                 r.ok[u] = l_ok[u];
             }
             r.edge = l_edge;
@@ -527,8 +542,13 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             const int e = k >> 2, i2 = k & 3, eo = e & 1;
             constexpr bool silu = PRO == PRO_AFFINE_SILU;
             if (sl == 0) {
-                qv0 = r.raw[u][2 * i2][e];
-                qv1 = r.raw[u][2 * i2 + 1][e];
+                if constexpr (X16) {  // (pixel e of the four: half e % 2 of dword e / 2)
+                    qv0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.raw[u][2 * i2] >> (16 * e)));
+                    qv1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.raw[u][2 * i2 + 1] >> (16 * e)));
+                } else {
+                    qv0 = r.raw[u][2 * i2][e];
+                    qv1 = r.raw[u][2 * i2 + 1][e];
+                }
                 if (PRO != PRO_NONE) {
                     qv0 = qv0 * ad4[u][i2][0] + ad4[u][i2][1];
                     qv1 = qv1 * ad4[u][i2][2] + ad4[u][i2][3];
@@ -1040,7 +1060,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     constexpr int SEGW = TW / 32;
     static_assert(ONEACC || ((NQ == 4 || NQ == 2) && RESQ == NQ - 1), "all quarters but the first wait in LDS");
     float bias_e[MR * 4];             // this lane's biases of the tile whose epilogue is in progress
-    f32x4 rv_e[4] = {};               // residual of the quarter that is processed next
+    using RV = std::conditional_t<Y16, unsigned long long, f32x4>;  // four pixels of one channel of the residual, as stored (fp16: one 64-bit scalar)
+    using gcrv = const RV __attribute__((address_space(1)))*;
+    using grv = RV __attribute__((address_space(1)))*;
+    auto rv_f32 = [&](const RV& r) __attribute__((always_inline)) {
+        if constexpr (Y16) {
+            return f32x4{(float)__builtin_bit_cast(_Float16, (unsigned short)r), (float)__builtin_bit_cast(_Float16, (unsigned short)(r >> 16)),
+                         (float)__builtin_bit_cast(_Float16, (unsigned short)(r >> 32)), (float)__builtin_bit_cast(_Float16, (unsigned short)(r >> 48))};
+        } else {
+            return r;
+        }
+    };
+    RV rv_e[4] = {};                  // residual of the quarter that is processed next
     float cs[4] = {}, cq[4] = {};     // fp32 statistics of a half's first quarter, waiting for its second
     float amax_e = 0.f;
     int pe_b = 0, pe_th = 0, pe_tw = 0, pe_cot = 0;
@@ -1054,12 +1085,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         asm volatile("" : "+v"(ln));
         return ln;
     };
-    auto res_request_to = [&](f32x4 (&rv)[4], auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) {
+    auto res_request_to = [&](RV (&rv)[4], auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) {
         if (!p.res) return;
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
-        const gcf4 ru = (gcf4)(p.res + b * p.res_bs + (long)(cot * COT) * HW);
+        const gcrv ru = (gcrv)(reinterpret_cast<const unsigned char*>(p.res) + ((long)b * p.res_bs + (long)(cot * COT) * HW) * YE);
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) rv[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
     };
@@ -1089,17 +1120,25 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             for (int j = 0; j < 4; ++j) dst[k8 * 256 + (j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
     };
     // bias, residual, scale, store, statistics of one turned quarter (t[k8]: 4 consecutive pixels of channel 8 k8 + lane / 8)
-    auto quarter = [&](auto QD, const f32x4 (&t)[4], const f32x4 (&rv)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+    auto quarter = [&](auto QD, const f32x4 (&t)[4], const RV (&rv)[4], int b, int th, int tw, int cot, int ln, float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
         const int s = wave * NR + n;
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
-        const gf4 yu = (gf4)(p.y + b * p.y_bs + (long)(cot * COT) * HW);
+        const grv yu = (grv)(reinterpret_cast<unsigned char*>(p.y) + ((long)b * p.y_bs + (long)(cot * COT) * HW) * YE);
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             f32x4 v = t[k8] * wsc + bias_e[m * 4 + k8];
-            v = rv[k8] + v;  // (without a residual the buffers stay zero -- res_request_to returns before it writes them: no select per element)
-            v *= sc_blk;     // (1.0f without p.scale: exact)
-            (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
+            v = rv_f32(rv[k8]) + v;  // (without a residual the buffers stay zero -- res_request_to returns before it writes them: no select per element)
+            v *= sc_blk;             // (1.0f without p.scale: exact)
+            if constexpr (Y16) {     // stored as fp16 (RNE); the statistics and the range maximum are those of the stored values
+                using f32x2 = __attribute__((ext_vector_type(2))) float;
+                const RV pk = (RV)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, f16x2)) |
+                              ((RV)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, f16x2)) << 32);
+                (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = pk;
+                v = rv_f32(pk);
+            } else {
+                (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
+            }
             if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);
             pq[k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -1130,7 +1169,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     };
     // deferred quarter S (1..3) of the pending tile; its residual is in rv (between chunks: rv_e, and the next quarter's is
     // requested here; at the block's end all three are requested up front)
-    auto slice_rv = [&](auto SS, const f32x4 (&rv)[4], auto NEXT) __attribute__((always_inline)) {
+    auto slice_rv = [&](auto SS, const RV (&rv)[4], auto NEXT) __attribute__((always_inline)) {
         constexpr int S = decltype(SS)::value;
         const int ln = fresh_lane();
         f32x4 t[4];
@@ -1167,9 +1206,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 if constexpr (EPI2) {
                     // the residual of quarters 0 and 1 by LDS-DMA into the wave's two waiting slots (4 KiB each: block k8 at 1 KiB k8, lane L's
                     // four pixels at 16 L -- the turned layout, read back with one ds_read_b128 per block); no register is written
-                    if (p.res) {
-                        res_dma(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
-                        res_dma(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
+                    if constexpr (!Y16) {
+                        if (p.res) {
+                            res_dma(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
+                            res_dma(ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
+                        }
                     }
                 } else if constexpr (NR != 4) res_request(ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
             }
@@ -1190,10 +1231,15 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     stamp(7);
                     const int ln = fresh_lane();
                     const int l31e = ln & 31, hie = ln >> 5;
-                    f32x4 rvA[4] = {}, rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
+                    RV rvA[4] = {}, rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
                     // the DMA of this tile's last chunk has had the chunk to land; hipcc does not see it: an explicit wait, in front of every
                     // memory operation of the tile's end (nothing else of this wave is in flight: the wait is for the DMA alone)
-                    if (p.res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (!Y16) {
+                        if (p.res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {  // (an fp16 residual has no 8-byte LDS-DMA form: the first two quarters' residual is requested here, like the others)
+                        res_request_to(rvA, ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
+                        res_request_to(rv1, ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
+                    }
                     res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
                     // (eight-row tile: the fourth buffer is requested behind quarter 0, whose accumulator registers it takes -- requested here it
                     // was spilled behind vmcnt(0))
@@ -1205,14 +1251,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         for (int k8 = 0; k8 < 4; ++k8) bias_e[m * 4 + k8] = btab[m * 32 + k8 * 8];
                     };
                     bias_load(ic<0>{});
-                    if (p.res) {
+                    if constexpr (!Y16) {
+                        if (p.res) {
 #pragma unroll
-                        for (int k8 = 0; k8 < 4; ++k8) {
-                            rvA[k8] = *reinterpret_cast<const f32x4*>(dump + k8 * 256 + ln * 4);
-                            rv1[k8] = *reinterpret_cast<const f32x4*>(dump + 1024 + k8 * 256 + ln * 4);
+                            for (int k8 = 0; k8 < 4; ++k8) {
+                                rvA[k8] = *reinterpret_cast<const f32x4*>(dump + k8 * 256 + ln * 4);
+                                rv1[k8] = *reinterpret_cast<const f32x4*>(dump + 1024 + k8 * 256 + ln * 4);
+                            }
                         }
                     }
-                    auto do_q = [&](auto QD, f32x4 (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+                    auto do_q = [&](auto QD, RV (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
                         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
                         f32x4 t[4];
 #pragma unroll
@@ -1276,7 +1324,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             // the waiting row block (quarters 6, 7): both behind the next tile's FIRST chunk -- quarter 6's residual was requested at the
             // tile's end, quarter 7's is requested here and has quarter 6's ~1.5 k cycles to arrive; nothing but that residual and four
             // biases stays alive through a chunk (a statistics carry between two slices was spilled and re-read behind vmcnt(0))
-            auto slice_w = [&](const f32x4 (&rv6)[4], f32x4 (&rv7)[4], auto REQ) __attribute__((always_inline)) {
+            auto slice_w = [&](const RV (&rv6)[4], RV (&rv7)[4], auto REQ) __attribute__((always_inline)) {
                 const int ln = fresh_lane();
                 if constexpr (decltype(REQ)::value) res_request_to(rv7, ic<7>{}, pe_b, pe_th, pe_tw, pe_cot, ln);
                 float ps0[4], pq0[4], ps1[4], pq1[4];
@@ -1312,7 +1360,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         asm volatile("" : "=v"(fa0[1][0]), "=v"(fa0[1][1]), "=v"(fb0[1][0]), "=v"(fb0[1][1]), "=v"(fb0[1][2]), "=v"(fb0[1][3]));
                         asm volatile("" : "=v"(fa1[0]), "=v"(fa1[1]), "=v"(fb1[0]), "=v"(fb1[1]), "=v"(fb1[2]), "=v"(fb1[3]));
                     }
-                    f32x4 rv7[4] = {};
+                    RV rv7[4] = {};
                     slice_w(rv_e, rv7, ic<1>{});
                     frag_all(xb1, lds_w0, ic<1>{});  // (chunk q + 1: x buffer 1, stage 3 (q + 1) in ring slot 0, h buffer 1)
                 }
@@ -1331,18 +1379,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     };
                     // (eight-row tile: nothing of the epilogue lives through the MFMA loop -- its first residual buffer is local to the tile's end;
                     // rv_e, which must keep its zeros for launches without a residual, costs the other tiles 16 registers all along)
-                    f32x4 rv0l[4] = {};
-                    auto& rvA = [&]() -> f32x4 (&)[4] { if constexpr (NR == 4) return rv0l; else return rv_e; }();
+                    RV rv0l[4] = {};
+                    auto& rvA = [&]() -> RV (&)[4] { if constexpr (NR == 4) return rv0l; else return rv_e; }();
                     if constexpr (NR == 4) res_request_to(rvA, ic<0>{}, e_b, e_th, e_tw, e_cot, ln);
                     bias_request(ic<0>{});
                     bias_request(ic<1>{});  // (the eight-row tile has two row blocks: all of its biases)
-                    f32x4 rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
+                    RV rv1[4] = {}, rv2[4] = {}, rv3[4] = {};
                     res_request_to(rv1, ic<1>{}, e_b, e_th, e_tw, e_cot, ln);
                     res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
                     // (eight-row tile: the fourth buffer is requested behind quarter 0, whose accumulator registers it takes -- requested here it
                     // was spilled behind vmcnt(0))
                     if constexpr (NR != 4) res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
-                    auto do_q = [&](auto QD, f32x4 (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
+                    auto do_q = [&](auto QD, RV (&rv)[4], float (&ps)[4], float (&pq)[4]) __attribute__((always_inline)) {
                         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
                         f32x4 t[4];
 #pragma unroll
@@ -1425,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 // (the block's last tile has nothing left to hide its deferred quarters behind: their residuals are requested now, into
                 // the registers the second accumulator has just left, and the quarters follow right below)
                 const bool last_tile = e_item + 1 == nIt;
-                f32x4 rv2[4] = {}, rv3[4] = {};
+                RV rv2[4] = {}, rv3[4] = {};
                 if constexpr (NQ == 4) {
                     if (last_tile) {
                         res_request_to(rv2, ic<2>{}, e_b, e_th, e_tw, e_cot, ln);
@@ -1622,9 +1670,9 @@ hipError_t launch_pack_conv_f16x2(const float* w, float* dst, int Cout, int Cin,
     return hipGetLastError();
 }
 
-template <int PRO, int NPLK, int MRK, int NRK>
+template <int PRO, int NPLK, int MRK, int NRK, int IOM = 0>
 static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
-    auto kern = conv_f16x2_kernel<PRO, NPLK, MRK, NRK>;
+    auto kern = conv_f16x2_kernel<PRO, NPLK, MRK, NRK, IOM>;
     using GEO = f2::Geo<MRK, NRK>;
     // The whole LDS of the CU, whatever the tile needs (the 32-channel tile: 98 KiB): a persistent block must not share its CU with a
     // workgroup of ANOTHER process.  Next to a neighbour process whose workgroups hold LDS, the 32-channel tile -- the only tile that left
@@ -1663,6 +1711,16 @@ static hipError_t launch_f2_tile(const ConvParams& p, hipStream_t s) {
     }
     {
     if (p.pieces == 1) {  // one fp16 product per MAC (the reduced-precision bulk mode)
+        const int iom = (p.x16 ? 1 : 0) | (p.y16 ? 2 : 0);  // fp16 storage of the input / of the output and residual
+        if (iom) {  // (the residual blocks' convolutions -- GroupNorm + SiLU input -- and the plain-input down- / up-sampling convolutions)
+            if (p.prologue == PRO_AFFINE_SILU) {
+                if (iom == 1) return launch_f2<PRO_AFFINE_SILU, 1, MRK, NRK, 1>(p, tiles, s);
+                if (iom == 2) return launch_f2<PRO_AFFINE_SILU, 1, MRK, NRK, 2>(p, tiles, s);
+                return launch_f2<PRO_AFFINE_SILU, 1, MRK, NRK, 3>(p, tiles, s);
+            }
+            if (p.prologue == PRO_NONE && iom == 3) return launch_f2<PRO_NONE, 1, MRK, NRK, 3>(p, tiles, s);
+            return hipErrorInvalidValue;
+        }
         switch (p.prologue) {
             case PRO_NONE: return launch_f2<PRO_NONE, 1, MRK, NRK>(p, tiles, s);
             case PRO_AFFINE: return launch_f2<PRO_AFFINE, 1, MRK, NRK>(p, tiles, s);
@@ -1710,6 +1768,7 @@ hipError_t launch_conv_f16x2(const ConvParams& p_in, hipStream_t s) {
     if (!conv_f16x2_supported(p.Cin, p.Cout, p.taps, p.H, p.W, p.co_tile, p.px_rows)) return hipErrorInvalidValue;
     if (p.x.p1 && p.x.c0 % f2::CK) return hipErrorInvalidValue;  // a chunk must not straddle the concat seam
     if (p.prologue != PRO_NONE && p.prologue != PRO_PRESPLIT && p.aff == nullptr && p.gn_partial == nullptr) return hipErrorInvalidValue;
+    if ((p.x16 || p.y16) && p.pieces != 1) return hipErrorInvalidValue;  // (fp16 storage exists in the one-plane mode only)
     if (p.gn_partial && (p.aff != nullptr || p.gn_cpg * 8 != p.Cin || !conv_f16x2_fold_supported(p, 8, p.gn_slots))) return hipErrorInvalidValue;
     if (p.prologue == PRO_PRESPLIT && ((p.co_tile != 64 && p.co_tile != 32) || p.px_rows != 4 || p.x.p1 != nullptr)) return hipErrorInvalidValue;
 #ifndef F2_PROF

@@ -361,8 +361,9 @@ struct Arena {
 struct Tensor {
     float* p = nullptr;
     int C = 0, H = 0, W = 0;
-    long bs() const { return (long)C * H * W; }
-    size_t bytes(int B) const { return (size_t)B * C * H * W * sizeof(float); }
+    bool f16 = false;  // stored as fp16 (the one-plane mode's activation storage: ConvParams::x16 / y16); `p` stays typed float*
+    long bs() const { return (long)C * H * W; }  // batch stride in ELEMENTS
+    size_t bytes(int B) const { return (size_t)B * C * H * W * (f16 ? 2 : sizeof(float)); }
 };
 
 inline Src src1(const Tensor& t) { return Src{t.p, nullptr, t.C, 0, t.bs(), 0}; }
@@ -476,7 +477,8 @@ struct Ctx {
                 size_t scale_off, bool has_scale, float* dst = nullptr, const Sink* sink = nullptr, int goff = 0,
                 bool res_broadcast = false, bool input_bounded = false,  // input_bounded: its producer tracked max|x| in the range flag
                 bool track_out = false,                                 // track_out: record max|y| there (precision mode 2 only)
-                const NormSpec* ns = nullptr) {                         // ns: `aff` comes from this GroupNorm (aff must be nullptr)
+                const NormSpec* ns = nullptr,                           // ns: `aff` comes from this GroupNorm (aff must be nullptr)
+                bool x16 = false, bool y16 = false) {                   // fp16 storage of the input / of the output (+ residual): act16(L) launches only
         // (decided in the dry walk as well, from shapes and the batch alone: the allocation sequence must be the same in both walks)
         bool fold = false;
         float2* own_aff = nullptr;
@@ -498,6 +500,7 @@ struct Ctx {
         y.C = L.cout;
         y.H = H;
         y.W = W;
+        y.f16 = y16;
         y.p = dst ? dst : (float*)ar->alloc(y.bytes(B));
         // (decided in the dry walk as well: the consumer's choice between finalize and the streaming pass changes the
         // allocation sequence, which must be the same in both walks)
@@ -546,6 +549,8 @@ struct Ctx {
                 p.co_tile = L.f2_cot;
                 p.px_rows = L.f2_rows;
                 p.pieces = h->conv_pieces;
+                p.x16 = x16;
+                p.y16 = y16;
                 if (fold) {
                     const Sink& k = *ns->stats;
                     p.gn_partial = k.p;
@@ -619,11 +624,20 @@ struct Ctx {
 
     // efficient_unet.py:95-110.  `in_stats`: fused statistics of x (if its producer left them);
     // `out` / `out_goff`: where the statistics of this block's output go (the next GroupNorm's sink).
+    // fp16 storage (round 5): in the one-plane mode (the reference's autocast counterpart) the tensor between a residual block's two
+    // convolutions is stored as fp16 -- what autocast stores there (/root/reference/sample_and_save.py:45,70) -- when both run on
+    // conv_f16x2 (R2DM_FP16_STORAGE=0: fp32 everywhere, as until round 4)
+    bool act16(const ConvLayer& L) const {
+        static const bool on = !getenv("R2DM_FP16_STORAGE") || atoi(getenv("R2DM_FP16_STORAGE")) != 0;
+        return on && h->conv_pieces == 1 && L.f2;
+    }
+
     Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,
                           bool track_out = false, bool skip_bounded = false) {
         const NormSpec n1{&in_stats, blob(r.g1), blob(r.b1), nullptr};
         Sink s1 = make_sink(r.cout, H, W);
-        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, nullptr, nullptr, 0, false, nullptr, &s1, 0, false, false, false, &n1);
+        const bool t1_16 = act16(r.conv1) && act16(r.conv2) && s1.p != nullptr;  // (the streaming statistics pass reads fp32)
+        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, nullptr, nullptr, 0, false, nullptr, &s1, 0, false, false, false, &n1, false, t1_16);
         const NormSpec n2{&s1, nullptr, nullptr, proj + r.ada_row};
         Tensor skip;
         const Tensor* res;
@@ -638,7 +652,7 @@ struct Ctx {
             ident.W = W;
             res = &ident;
         }
-        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, nullptr, res, r.scale, true, nullptr, out, out_goff, false, false, track_out, &n2);
+        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, nullptr, res, r.scale, true, nullptr, out, out_goff, false, false, track_out, &n2, t1_16, false);
         drop_sink(s1);
         drop(t1);
         if (r.has_skip) drop(skip);
@@ -1162,6 +1176,12 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.Cin = cin;
     p.Cout = cout;
     p.prologue = prologue;
+    // per-kernel tests of the fp16 activation storage (conv_f16x2.hip, one-plane mode): R2DM_TEST_IO16 = 1 (x holds fp16), 2 (y and the
+    // residual hold fp16) or 3 -- the caller passes tensors of that type behind the float pointers
+    if (const char* e = getenv("R2DM_TEST_IO16"); e && p.algo == ALGO_F16X2 && p.pieces == 1) {
+        p.x16 = atoi(e) & 1;
+        p.y16 = (atoi(e) >> 1) & 1;
+    }
     // perf probe (scripts/conv_phases.py): per-block s_memtime stamps into a caller-provided device buffer
     if (const char* e = getenv("R2DM_CONV_PROF_PTR")) p.prof = (unsigned long long*)strtoull(e, nullptr, 0);
     // per-kernel tests / probes of the operand pre-pass (presplit.hip + conv_f16x2's PRO_PRESPLIT stagers): R2DM_F2_PRESPLIT=1

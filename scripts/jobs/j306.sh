@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5 evidence set r05a: rocprofv3 kernel trace + three PMC passes + bench lines + whole GPU suite + 256-step validation, on the round's code
+# round 5 evidence set (r05a: before the 32-channel tile; r05b: final code): rocprofv3 kernel trace + three PMC passes + bench lines + whole GPU suite + 256-step validation, on the round's code
 # (64 x 8 tile, round-5 tile end of the one-accumulator tiles, GroupNorm folded into its consumer)
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/j306; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${JOB:-j306}; mkdir -p $O
 cd /tmp
 A="--no-cpu-baseline --no-torch-baseline --no-exact-baseline --no-other-configs"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench_kt -- python $R/bench.py $A --prewarm-s 0.5 > $O/bench_kt.json 2> $O/bench_kt.err

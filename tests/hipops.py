@@ -14,13 +14,17 @@ def set_conv_pieces(n):
     _lib.check(_lib.lib().r2dm_set_conv_pieces(None, n))
 
 
-def conv2d_ring(x, w, b, aff=None, prologue=0, residual=None, scale=None):
+def conv2d_ring(x, w, b, aff=None, prologue=0, residual=None, scale=None, io16=0):
+    """io16 (with R2DM_TEST_IO16 set to the same value by the caller): bit 0 -- x is a half tensor, bit 1 -- the residual is and y will be."""
     L = _lib.lib()
     B, cin, H, W = x.shape
     cout, k = w.shape[0], w.shape[-1]
-    x, w, b = _lib.f32c(x), _lib.f32c(w), _lib.f32c(b)
+    w, b = _lib.f32c(w), _lib.f32c(b)
+    x = x.detach().half().contiguous() if io16 & 1 else _lib.f32c(x)
+    if residual is not None:
+        residual = residual.detach().half().contiguous() if io16 & 2 else _lib.f32c(residual)
     packed = torch.empty(L.r2dm_conv_packed_elems(cout, cin, k, B, H, W), device=x.device)
-    y = torch.empty(B, cout, H, W, device=x.device)
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float16 if io16 & 2 else torch.float32)
     sc = None if scale is None else torch.tensor([scale], device=x.device, dtype=torch.float32)
     _lib.check(L.r2dm_conv2d_ring(x.data_ptr(), w.data_ptr(), b.data_ptr(), packed.data_ptr(), _lib.ptr(aff), prologue,
                                   _lib.ptr(residual), _lib.ptr(sc), y.data_ptr(), B, cin, cout, H, W, k, _st(x)))

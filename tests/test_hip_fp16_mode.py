@@ -91,6 +91,38 @@ def test_conv_one_product_tiles_are_bit_identical(H, cin, cout, h, w):
         assert torch.equal(outs[tile], outs["64"]), tile
 
 
+@pytest.mark.parametrize("tile", ["64", "32", "128", "64x8"])
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 128, 16, 256), (64, 64, 32, 512)])
+def test_conv_fp16_storage_is_exact(H, cin, cout, h, w, tile):
+    """Round 5: activations stored as fp16 in the one-plane mode, as the reference's autocast stores its convolution
+    outputs.  Storage is the ONLY change: on fp16-representable inputs a launch reading fp16 gives bit for bit what the same launch reading the
+    same values as fp32 gives, and a launch writing fp16 gives exactly RNE_f16 of the fp32 launch's output -- every tile, with GroupNorm +
+    SiLU prologue, fp16 residual and scale."""
+    import os
+
+    B = 3
+    x, wt, b = rnd(1, B, cin, h, w).half().float(), rnd(2, cout, cin, 3, 3) / math.sqrt(9 * cin), rnd(3, cout)
+    res = rnd(4, B, cout, h, w).half().float()
+    aff = torch.stack([torch.rand(B, cin) + 0.5, torch.randn(B, cin) * 0.3], -1).contiguous()
+    saved = {k: os.environ.get(k) for k in ("R2DM_F2_CO_TILE", "R2DM_TEST_IO16")}
+    H.set_conv_pieces(1)
+    out = {}
+    try:
+        os.environ["R2DM_F2_CO_TILE"] = tile
+        for io in (0, 1, 2, 3):
+            os.environ["R2DM_TEST_IO16"] = str(io)
+            out[io] = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), aff=aff.to(DEV), prologue=2, residual=res.to(DEV), scale=0.70710678, io16=io).cpu()
+    finally:
+        H.set_conv_pieces(2)
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert out[0].dtype == torch.float32 and out[3].dtype == torch.float16
+    assert torch.equal(out[1], out[0])                       # fp16 input: the same values, the same arithmetic
+    assert torch.equal(out[2], out[0].half()) and torch.equal(out[3], out[0].half())  # fp16 output: the fp32 result, rounded once
+
+
 @pytest.mark.parametrize("pro", [1, 2])
 def test_conv_one_product_with_fused_prologue(O, H, pro):
     import torch.nn.functional as F

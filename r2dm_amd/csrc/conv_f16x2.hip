@@ -149,6 +149,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem;
 
+    // A block OWNS its CU (round 5): every wave allocates all 256 registers (a clobber of v255 costs nothing else -- occupancy is one block
+    // per CU either way) and the launcher pads the LDS request to >= 156 KiB, so no wave of any other kernel or process is ever resident on
+    // the same CU.  Why: next to ANOTHER PROCESS's waves on its CU the one-plane 32-channel tile (181 registers) ended 12-17 of 20 runs of
+    // 600 forwards in a GPU memory fault at a wild address (never a wrong result); with the CU to itself 0 of 70, all modes
+    // (profiles/r05_coresidency.txt: what was ruled out, and that the cause is NOT identified).  -DF2_SHARE_CU: the allocation hipcc computes.
+#ifndef F2_SHARE_CU
+    asm volatile("" ::: "v255");
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,6 +463,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
         };
         auto gload_px = [&](RAW& d, const unsigned char* base, unsigned voff) __attribute__((always_inline)) {
+#ifdef F2_NO_PXLOAD  // fault bisection (wrong results): no pixel load is issued
+            asm volatile("" : "=v"(d) : "v"(voff), "s"(base));
+            return;
+#endif
             if constexpr (X16) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
         };
@@ -1130,6 +1142,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             f32x4 v = t[k8] * wsc + bias_e[m * 4 + k8];
             v = rv_f32(rv[k8]) + v;  // (without a residual the buffers stay zero -- res_request_to returns before it writes them: no select per element)
             v *= sc_blk;             // (1.0f without p.scale: exact)
+#ifdef F2_NO_STORE  // fault bisection (wrong results): nothing is stored
+            if (ln >= 0) { ps[k8] = v[0]; pq[k8] = v[1]; continue; }
+#endif
             if constexpr (Y16) {     // stored as fp16 (RNE); the statistics and the range maximum are those of the stored values
                 using f32x2 = __attribute__((ext_vector_type(2))) float;
                 const RV pk = (RV)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, f16x2)) |
@@ -1147,6 +1162,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     auto half_stats = [&](auto M, const float (&s0)[4], const float (&q0)[4], const float (&s1)[4], const float (&q1)[4], int b, int th,
                           int tw, int cot, int ln) __attribute__((always_inline)) {
         if (!p.stat) return;
+#ifdef F2_NO_STORE
+        if (ln >= 0) return;
+#endif
         double st_s[4], st_q[4];
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {  // (four pixels in fp32, fp64 beyond: conv_epilogue.h)
@@ -1518,7 +1536,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));
                     if constexpr (NPLK == 2) asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]), "=v"(acl[1][0]), "=v"(acl[1][1]));
                 } else {
-                    asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acl[0][0]), "=v"(acl[0][1]));
+                    asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]));
+                    if constexpr (ACC2) asm volatile("" : "=v"(acl[0][0]), "=v"(acl[0][1]));  // (one plane: acl is a [1][1] dummy -- indexing [0][1] there was out of bounds)
                 }
                 if (++e_item < nIt) decode(e_item, e_cot, e_b, e_th, e_tw);
                 // first fragments of the next tile (its chunk 0 sits in x buffer 0, stage 3(q+1) in the ring: published at

@@ -548,7 +548,7 @@ struct Ctx {
                 p.wscale = blob(L.ws_f2) + 1;
                 p.co_tile = L.f2_cot;
                 p.px_rows = L.f2_rows;
-                p.pieces = h->conv_pieces;
+                p.pieces = (L.f2_cot == 32 && narrow_split()) ? 2 : h->conv_pieces;
                 p.x16 = x16;
                 p.y16 = y16;
                 if (fold) {
@@ -611,8 +611,8 @@ struct Ctx {
                 }
             }
             if (g_debug_sync)
-                fprintf(stderr, "[r2dm] conv algo %d %d->%d taps %d co_tile %d %dx%d B %d pro %d x %p/%p (c0 %d) y %p res %p aff %p stat %p ws [%p, +%zu)\n", p.algo, p.Cin,
-                        p.Cout, p.taps, p.co_tile, H, W, B, pro, (const void*)p.x.p0, (const void*)p.x.p1, p.x.c0, (void*)p.y, (const void*)p.res, (const void*)p.aff,
+                fprintf(stderr, "[r2dm] conv algo %d %d->%d taps %d co_tile %d %dx%d B %d pro %d w %p bias %p gn %p blob [%p, +%zu) x %p/%p (c0 %d) y %p res %p aff %p stat %p ws [%p, +%zu)\n", p.algo, p.Cin,
+                        p.Cout, p.taps, p.co_tile, H, W, B, pro, (const void*)p.w, (const void*)p.bias, (const void*)p.gn_partial, (void*)h->blob, h->blob_floats * 4, (const void*)p.x.p0, (const void*)p.x.p1, p.x.c0, (void*)p.y, (const void*)p.res, (const void*)p.aff,
                         (void*)p.stat, (void*)ar->base, ar->cap);
             note(launch_conv(p, st), "conv");
             if (e1) (void)hipEventRecord(e1, st);
@@ -629,7 +629,12 @@ struct Ctx {
     // conv_f16x2 (R2DM_FP16_STORAGE=0: fp32 everywhere, as until round 4)
     bool act16(const ConvLayer& L) const {
         static const bool on = !getenv("R2DM_FP16_STORAGE") || atoi(getenv("R2DM_FP16_STORAGE")) != 0;
-        return on && h->conv_pieces == 1 && L.f2;
+        return on && h->conv_pieces == 1 && L.f2 && !(L.f2_cot == 32 && narrow_split());
+    }
+    // (experiment switch, round 5) layers packed for the 32-channel tile run the two-plane kernel in every precision mode
+    static bool narrow_split() {
+        static const bool on = getenv("R2DM_F2_NARROW_SPLIT") && atoi(getenv("R2DM_F2_NARROW_SPLIT")) != 0;
+        return on;
     }
 
     Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,

@@ -228,12 +228,14 @@ def hipblaslt_reference(dev):
     return {"tflops": 2 * 8192 ** 3 * n / dt / 1e12, "board": bs.summary(), "what": "torch.matmul bf16 8192x8192x8192 (hipBLASLt), 1 s"}
 
 
-def pmc_traffic():
+def pmc_traffic(what="bytes_per_launch"):
     """HBM bytes per conv launch from the committed PMC passes (scripts/summarize_profile.py); PMC counters cannot be
-    collected from inside the timed process, so this is the figure of the last profiled run of this same command."""
+    collected from inside the timed process, so this is the figure of the last profiled run of this same command
+    (what="source": the evidence set it was taken from)."""
     try:
         with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
-            return float(json.load(f)["bytes_per_launch"])
+            d = json.load(f)
+            return float(d["bytes_per_launch"]) if what == "bytes_per_launch" else str(d[what])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -412,8 +414,8 @@ def main():
         line["roofline"] = {
             "bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": pmc_traffic() if args.config == 1 else None,
-            "traffic_source": "replayed: profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, round 4; PMC counters "
-                              "cannot be collected inside the timed process)" if args.config == 1 else None,
+            "traffic_source": "replayed: profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, evidence set %s; "
+                              "PMC counters cannot be collected inside the timed process)" % pmc_traffic("source") if args.config == 1 else None,
             "peak_definition": "dominant kernel %s: dense 16-bit MFMA peak 2500 TF/s (2.4 GHz) / %d matrix products per algorithmic "
                                "fp32 product" % (dom["kernel"], dom.get("products_per_fp32_product", 1)),
             "frac_of_round1_peak": dom["tflops"] / (PEAK_BF16 / 6 / 1e12),  # round 1 priced the same algorithmic FLOPs at 2500/6 = 416.7 TF/s

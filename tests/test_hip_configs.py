@@ -285,21 +285,28 @@ def test_rccl_backend_executes_on_this_gpu():
 
 
 @pytest.mark.skipif(os.environ.get("R2DM_CONV_ALGO", "").startswith("f"), reason="fp32-MFMA algorithm forced")
-@pytest.mark.parametrize("batch,res,reps", [(2, (64, 1024), 80), (8, (64, 1024), 40), (2, (128, 2048), 40)])
-def test_forwards_next_to_a_second_process(tmp_path, batch, res, reps):
+@pytest.mark.parametrize("batch,res,reps,neighbour,modes", [
+    (2, (64, 1024), 80, "512,512,8,128,1,8", ("fp32", "fp32-bf16x3", "fp16")),
+    (8, (64, 1024), 40, "512,512,8,128,1,8", ("fp32", "fp32-bf16x3", "fp16")),
+    (2, (128, 2048), 40, "512,512,8,128,1,8", ("fp32", "fp32-bf16x3", "fp16")),
+    (2, (64, 1024), 600, "64,2,64,1024,3,8", ("fp16",)),  # round 5: the trigger of the one-plane 32-channel tile's fault (17 of 20 such runs)
+])
+def test_forwards_next_to_a_second_process(tmp_path, batch, res, reps, neighbour, modes):
     """Round 2 saw wrong forwards whenever a second process computed on the same GPU; round 3 traced it to ONE kernel (the old
     LDS-tiled out_conv, now removed: profiles/r03_shared_gpu.txt) and found the most effective trigger: a second process
     looping a 55 KB-LDS GEMM-like kernel (147 of 150 forwards wrong with the old kernel).  Every precision mode of the
     current library next to that neighbour: 0 forwards may differ bitwise from the one computed alone
     (/root/reference/sample_and_save.py:37-46,75: results must not depend on the process layout).  Round 4: also at
-    batch 8 (BASELINE configs[1]: the 128-channel-tile kernels run there) and on the per-GPU shard of configs[4] (128x2048, batch 2)."""
+    batch 8 (BASELINE configs[1]: the 128-channel-tile kernels run there) and on the per-GPU shard of configs[4] (128x2048, batch 2).
+    Round 5: next to a looping out_conv (the direct kernel: 133 registers, no LDS -- it fits beside any block that leaves registers free)
+    the one-plane 32-channel tile of conv_f16x2.hip died of a GPU memory fault in 17 of 20 runs of 600 fp16-mode forwards; since a
+    conv_f16x2 block owns its CU, 0 of 70 (profiles/r05_coresidency.txt) -- the last case repeats that run."""
     import time
 
     ready = tmp_path / "ready"
-    env = dict(os.environ, SHAPE="512,512,8,128,1,8", SECS="150", READY_FILE=str(ready))
+    env = dict(os.environ, SHAPE=neighbour, SECS="150", READY_FILE=str(ready))
     ddpm = build(max_batch=batch, resolution=res)
     x, c = rnd(91, batch, 2, *res).to(DEV), torch.linspace(-3.0, 1.0, batch, device=DEV)
-    modes = ("fp32", "fp32-bf16x3", "fp16")
     alone = {}
     for m in modes:
         ddpm.model.set_precision(m)

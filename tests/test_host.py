@@ -383,3 +383,39 @@ def test_blob_layout_fingerprint():
     assert h2 == m2b.model.packed_layout_hash() and h2 != h8 and h2 != 0
     with pytest.raises(R2DMError, match="layout"):
         m8.model.adopt_packed_weights(torch.empty(m8.model.packed_weight_bytes(), dtype=torch.uint8), layout_hash=h2)
+
+
+def test_conv_f16x2_blocks_own_their_cu(tmp_path):
+    """Round 5 (profiles/r05_coresidency.txt): next to ANOTHER PROCESS's waves on its CU the one-plane 32-channel tile of
+    conv_f16x2.hip ended most 600-forward runs in a GPU memory fault; with the CU to itself never.  The invariant since then: every
+    conv_f16x2_kernel instantiation allocates all 256 vector registers (two waves per SIMD = the whole file) and every launch requests
+    >= 156 KiB of LDS -- nothing else fits on a CU that runs one of its blocks.  Checked here on the BUILT code objects (their metadata
+    notes), so a compiler or source change that shrinks the allocation fails on the CPU suite
+    (/root/reference/sample_and_save.py:37-46: results must not depend on what else the GPU runs)."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "r2dm_amd", "libr2dm_hip.so")
+    if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("llvm-objdump / llvm-readelf of the ROCm toolchain not present")
+    if not os.path.exists(lib):
+        pytest.skip("libr2dm_hip.so not built")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    counts = []
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        if "conv_f16x2_kernel" not in notes:
+            continue
+        # one metadata record per kernel: ".name: <mangled>" ... ".vgpr_count: N" (keys sorted alphabetically inside a record)
+        for rec in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", rec).group(1)
+            if "4r2dm17conv_f16x2_kernel" in name:  # (not pack_conv_f16x2_kernel)
+                counts.append((name, int(re.search(r"\.vgpr_count:\s+(\d+)", rec).group(1)), int(re.search(r"\.agpr_count:\s+(\d+)", "- .agpr_count:" + rec).group(1))))
+    assert len(counts) >= 30, "conv_f16x2_kernel instantiations not found in the library's code objects"
+    assert all(v + a == 256 for _, v, a in counts), [c for c in counts if c[1] + c[2] != 256][:4]
+    src = open(os.path.join(ROOT, "r2dm_amd", "csrc", "conv_f16x2.hip")).read()
+    assert re.search(r"LDS_TOTAL >= 156 \* 1024 \|\| lds_exact \? GEO::LDS_TOTAL : 156 \* 1024", src), "the launcher's LDS padding"

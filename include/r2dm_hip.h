@@ -171,6 +171,13 @@ int r2dm_fir_down2(const float* x, float* y, int32_t batch, int32_t channels, in
                    void* stream);
 int r2dm_fir_up2(const float* x, float* y, int32_t batch, int32_t channels, int32_t height, int32_t width,
                  void* stream);
+/* ops.Resample(down=2) that also leaves the GroupNorm statistics of its OUTPUT (nn.GroupNorm(groups, C) behind it:
+ * models/efficient_unet.py:95-97 behind :135) in the convolution epilogues' slot grid -- stat: (B, groups, slots, 2) doubles
+ * [sum, sum of squares], slots = r2dm_fir_down2_stat_slots() (0: geometry not supported, call r2dm_fir_down2); every slot is
+ * written, the sums of a (sample, group) over ALL its slots are the group's moments.  Kernel-level test hook of the engine's path. */
+int32_t r2dm_fir_down2_stat_slots(int32_t channels, int32_t groups, int32_t height, int32_t width);
+int r2dm_fir_down2_stats(const float* x, float* y, double* stat, int32_t batch, int32_t channels, int32_t groups,
+                         int32_t height, int32_t width, void* stream);
 /* attention core of nn.MultiheadAttention on channel-major qkv (B,3C,N) -> (B,C,N)
  * (models/efficient_unet.py:34-38,46) */
 int r2dm_attention(const float* qkv, float* out, int32_t batch, int32_t channels, int32_t heads, int32_t tokens,

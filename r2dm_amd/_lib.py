@@ -86,6 +86,8 @@ SIGNATURES = {
                                          c_float, _P]),
     "r2dm_affine_act": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
     "r2dm_fir_down2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    "r2dm_fir_down2_stat_slots": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "r2dm_fir_down2_stats": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "r2dm_fir_up2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "r2dm_attention": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "r2dm_time_embedding": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),

@@ -179,8 +179,11 @@ hipError_t launch_group_norm(const GNParams& p, hipStream_t s);
 hipError_t launch_gn_apply(const float* x, const float2* aff, float* y, int B, int C, long hw, int silu,
                            hipStream_t s);
 
+// stat != nullptr: the GroupNorm statistics of the OUTPUT (G groups) go to the convolution epilogues' slot grid
+// ([B][G][conv_stat_slots(H / 2, W / 2)][2] doubles); only where fir_down2_stat_slots(C, G, H, W) != 0
 hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
-                            hipStream_t s);
+                            hipStream_t s, double* stat = nullptr, int G = 0);
+int fir_down2_stat_slots(int C, int G, int H, int W);
 hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
                           hipStream_t s, int* range = nullptr);  // range[1]: running max |output| as float bits (may be nullptr)
 

@@ -6,6 +6,8 @@
 // no LDS: a thread owns 4 consecutive pixels of 2 rows, reads its input window straight from global memory (its
 // neighbours' lines: L1 / L2 hits) and takes the weights as wave-uniform scalar operands.
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 #include "wave_ops.h"
 
 namespace r2dm {
@@ -26,6 +28,9 @@ constexpr int TH = 4, TW = 64, XR = TH + 2, XS = TW + 2, CK = 8, MAXCO = 4;
 // staging: the LDS version above spent its time in 27 LDS reads per 18 FMAs and reached 1.6 TB/s of its 134 MB input;
 // this one reaches 2.4 TB/s (83 -> 57 us at batch 8; the 9 load instructions per thread and channel are its limit -- a DPP wave
 // shift for the neighbour pixels was tried and is not worth its select logic).  Block = 4 rows x 256 columns.
+// Round 5, tried and reverted: channel batches of 4 double-buffered by hand (inline-assembly loads, counted vmcnt, one batch of 48 loads
+// always in flight; 416 registers, one wave per SIMD as before): 52.5 -> 65.7 us at batch 8 (scripts/jobs/j340.sh) -- three 1 KiB-span
+// load instructions per (channel, row) keep the CU's address pipeline busy either way; more in flight only queues there.
 #ifndef DC_ROWS
 #define DC_ROWS 2
 #endif
@@ -147,27 +152,36 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
             for (int j = 0; j < 4; ++j) x[ci][k][1 + j] = ok ? v[j] : 0.f;
         }
     }
-    const float sc = p.scale ? *(gcf)p.scale : 1.0f;
-    const gcf wg = (gcf)p.w;
+    // Weights, biases and the scale through the SCALAR cache (constant address space: s_load).  As plain global pointers the compiler
+    // had to assume that this kernel's own stores may alias them: it fetched all 8 x 9 CI weights of a block with VECTOR loads (144
+    // registers of wave-uniform values: 228 registers, two waves per SIMD) and every bias with a vector load that the store behind it
+    // waited for with vmcnt(0) -- 64 serial L2 round trips per thread (round 5: ISA read; 58 us at batch 8 against ~30 us of HBM time).
+    using ccf = const float __attribute__((address_space(4)))*;
+    const float sc = p.scale ? *(ccf)p.scale : 1.0f;
+    const ccf wg = (ccf)p.w, bg = (ccf)p.bias;
     const long pix = (long)gr * W + gc;
     const int bpg = p.stat ? p.stat_cpg >> 3 : 1;  // 8-channel blocks per group
     const int S = p.stat_slots >> 1;
     double gs = 0.0, gq = 0.0;
-    for (int co0 = 0; co0 < p.Cout; co0 += 8) {
-        // the block's eight residual vectors first: a load behind a store may not pass it (the output may alias the residual as far
-        // as the compiler knows), and one L2 round trip per channel -- 64 in series per wave -- was a third of this kernel's time
-        // (87 -> 59 us at batch 8; requesting them a whole block early as well: 59 us, not kept)
-        f32x4 rv[8] = {};
-        if (p.res) {
+    // blockIdx.y: this block's share of the output channels (whole groups: launcher) -- twice / four times the waves for the same
+    // output stream; the 3 x 6 input windows are re-read per share (L2 hits: the input is 1/32 of the output)
+    const int cps = p.Cout / (int)gridDim.y, co_lo = (int)blockIdx.y * cps, co_hi = co_lo + cps;
+    // the block's eight residual vectors are requested one block AHEAD, in front of the previous block's stores: vmcnt retires in order,
+    // stores included, so a load requested behind eight stores is only usable once those stores are acknowledged
+    f32x4 rv[8] = {}, rn[8] = {};
+    auto res_fetch = [&](f32x4 (&r)[8], int co0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int o = 0; o < 8; ++o) rv[o] = *(gcf4)(p.res + b * p.res_bs + (long)(co0 + o) * HW + pix);
-        }
+        for (int o = 0; o < 8; ++o) r[o] = *(gcf4)(p.res + b * p.res_bs + (long)(co0 + o) * HW + pix);
+    };
+    if (p.res) res_fetch(rv, co_lo);
+    for (int co0 = co_lo; co0 < co_hi; co0 += 8) {
+        if (p.res && co0 + 8 < co_hi) res_fetch(rn, co0 + 8);
         float acc[8][4];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
-            const gcf wk = wg + (long)(co0 + o) * CI * 9;
+            const ccf wk = wg + (long)(co0 + o) * CI * 9;
 #pragma unroll
             for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            const float bo = ((gcf)p.bias)[co0 + o];
+            const float bo = bg[co0 + o];
             f32x4 v = f32x4{acc[o][0] + bo, acc[o][1] + bo, acc[o][2] + bo, acc[o][3] + bo};
             if (p.res) v = rv[o] + v;
             v *= sc;  // (1.0f without p.scale: exact)
@@ -191,6 +205,8 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
                 }
             }
         }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) rv[o] = rn[o];
         if (p.stat && ((co0 >> 3) + 1) % bpg == 0) {  // the group's last block: wave totals into the slot grid
             const double ts = wave_sum_f64(gs), tq = wave_sum_f64(gq);
             gs = gq = 0.0;
@@ -217,7 +233,14 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s) {
     if (p.Cout > dc::MAXCO) {  // the few-input kernel
         if (!conv_few_in_supported(p.Cin, p.Cout, p.taps, p.H, p.W) || p.prologue != PRO_NONE || p.x.p1 || p.range) return hipErrorInvalidValue;
         if (p.stat && (p.stat_cpg % 8 || p.Cout % p.stat_cpg || p.stat_slots != conv_stat_slots(p.H, p.W))) return hipErrorInvalidValue;
-        const unsigned nb = (unsigned)(((p.W + 255) / 256) * (p.H / 4) * p.B);
+        const unsigned nbx = (unsigned)(((p.W + 255) / 256) * (p.H / 4) * p.B);
+        // shares of the output channels (blockIdx.y): whole statistics groups of whole 8-channel blocks, up to four, while the launch has
+        // fewer than ~16 waves per CU
+        static const int max_split = getenv("R2DM_FEW_IN_SPLIT") ? atoi(getenv("R2DM_FEW_IN_SPLIT")) : 2;
+        const int unit = p.stat ? p.stat_cpg : 8;
+        unsigned split = 1;
+        while ((int)split * 2 <= max_split && p.Cout % ((int)split * 2 * unit) == 0 && nbx * split < 2048) split *= 2;
+        const dim3 nb(nbx, split);
         switch (p.Cin) {
             case 1: conv_few_in_kernel<1><<<nb, 256, 0, s>>>(p); break;
             case 2: conv_few_in_kernel<2><<<nb, 256, 0, s>>>(p); break;

@@ -692,12 +692,17 @@ struct Ctx {
         if (s.down) {
             Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, in_tracked);
             cur = make(s.cout, H / 2, W / 2);
-            if (!dry()) note(launch_fir_down2(t.p, t.bs(), cur.p, cur.bs(), B, s.cout, H, W, st), "fir_down2");
+            // the FIR pass leaves the statistics of its output for the first residual block's norm (resample.hip; where its geometry
+            // does not fit the slot grid: no fused statistics, the streaming pass)
+            Sink fs;
+            if (fir_down2_stat_slots(s.cout, h->cfg.gn_num_groups, H, W)) fs = make_sink(s.cout, H / 2, W / 2);
+            if (!dry()) note(launch_fir_down2(t.p, t.bs(), cur.p, cur.bs(), B, s.cout, H, W, st, fs.p, h->cfg.gn_num_groups), "fir_down2");
             drop(t);
             H /= 2;
             W /= 2;
             have = true;
-            carry = Sink{};  // the FIR output has no fused statistics: streaming pass
+            carry = fs;
+            carry_owned = fs.p != nullptr;
         }
         const int n = (int)s.res.size();
         for (int i = 0; i < n; ++i) {
@@ -1232,6 +1237,16 @@ int r2dm_affine_act(const float* x, const float* aff, float* y, int32_t B, int32
 
 int r2dm_fir_down2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
     HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream));
+    return 0;
+}
+
+int32_t r2dm_fir_down2_stat_slots(int32_t C, int32_t G, int32_t H, int32_t W) {
+    return fir_down2_stat_slots(C, G, H, W) ? conv_stat_slots(H / 2, W / 2) : 0;
+}
+
+int r2dm_fir_down2_stats(const float* x, float* y, double* stat, int32_t B, int32_t C, int32_t G, int32_t H, int32_t W, void* stream) {
+    if (!stat || !fir_down2_stat_slots(C, G, H, W)) return fail(1, "fir_down2_stats: geometry without a statistics variant");
+    HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream, stat, G));
     return 0;
 }
 

@@ -13,6 +13,13 @@
 
 namespace r2dm {
 
+// The [1,3,3,1]/8 window as ONE spelled-out chain of fused multiply-adds, shared by the three down-sampling kernels: left to the
+// compiler's contraction the same source expression came out differently in different kernels (round 5: the statistics variant and the
+// plain wide kernel differed in the last bit of some outputs, 2e-7 rms on the U-Net).
+__device__ __forceinline__ float fir4(float a, float b, float c, float d) {
+    return __builtin_fmaf(0.125f, d, __builtin_fmaf(0.375f, c, __builtin_fmaf(0.375f, b, 0.125f * a)));
+}
+
 // one thread -> two horizontally adjacent outputs; needs input columns 4t-1 .. 4t+4 of 4 rows
 __global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                         long ybs, int C, int H, int W) {
@@ -27,22 +34,20 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict_
         const float* xp = x + b * xbs + (long)c * H * W;
         const int cl = 4 * t - 1 < 0 ? W - 1 : 4 * t - 1;
         const int cr = 4 * t + 4 >= W ? 0 : 4 * t + 4;
-        float o0 = 0.f, o1 = 0.f;
+        float h0[4], h1[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int r = 2 * i + a - 1;
-            float h0 = 0.f, h1 = 0.f;
+            h0[a] = h1[a] = 0.f;
             if (r >= 0 && r < H) {
                 const float* row = xp + (long)r * W;
                 const f32x4 m = *reinterpret_cast<const f32x4*>(row + 4 * t);
                 const float l = row[cl], rr = row[cr];
-                h0 = 0.125f * l + 0.375f * m[0] + 0.375f * m[1] + 0.125f * m[2];
-                h1 = 0.125f * m[1] + 0.375f * m[2] + 0.375f * m[3] + 0.125f * rr;
+                h0[a] = fir4(l, m[0], m[1], m[2]);
+                h1[a] = fir4(m[1], m[2], m[3], rr);
             }
-            const float ka = (a == 0 || a == 3) ? 0.125f : 0.375f;
-            o0 += ka * h0;
-            o1 += ka * h1;
         }
+        const float o0 = fir4(h0[0], h0[1], h0[2], h0[3]), o1 = fir4(h1[0], h1[1], h1[2], h1[3]);
         float2* out = reinterpret_cast<float2*>(y + b * ybs + (long)c * Ho * Wo + (long)i * Wo + 2 * t);
         *out = make_float2(o0, o1);
     }
@@ -50,7 +55,34 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict_
 
 // one thread -> a 2 x 4 output patch (rows 2i, 2i+1 of the block's pair, columns 4t .. 4t+3): input columns 8t-1 .. 8t+8 of
 // 6 rows = 24 load instructions for 8 outputs.  (One output pair per thread was 12 loads for 2 outputs and bound by the CU's
-// address pipeline, not by HBM: 3.7 TB/s.)  Needs W % 8 == 0, H % 4 == 0; the generic kernel below takes the rest.
+// address pipeline, not by HBM: 3.7 TB/s.)  Needs W % 8 == 0, H % 4 == 0; the generic kernel above takes the rest.
+// xp: the input plane, i2: pair of output rows, t: quad of output columns; v[o]: output row 2 i2 + o, columns 4t .. 4t+3
+__device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, int H, int W, int i2, int t, f32x4 (&v)[2]) {
+    const int cl = 8 * t - 1 < 0 ? W - 1 : 8 * t - 1;
+    const int cr = 8 * t + 8 >= W ? 0 : 8 * t + 8;
+    float h[6][4];  // horizontally filtered rows 4 i2 - 1 .. 4 i2 + 4 at the four output columns
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const int r = 4 * i2 + a - 1;
+        if (r >= 0 && r < H) {
+            const float* row = xp + (long)r * W;
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + 8 * t), m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
+            const float l = row[cl], rr = row[cr];
+            h[a][0] = fir4(l, m0[0], m0[1], m0[2]);
+            h[a][1] = fir4(m0[1], m0[2], m0[3], m1[0]);
+            h[a][2] = fir4(m0[3], m1[0], m1[1], m1[2]);
+            h[a][3] = fir4(m1[1], m1[2], m1[3], rr);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[a][j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o)  // output row 2 i2 + o takes input rows (2 o) .. (2 o + 3) of the six; the generic kernel's chain (fir4):
+#pragma unroll                   // bit-identical results
+        for (int j = 0; j < 4; ++j) v[o][j] = fir4(h[2 * o][j], h[2 * o + 1][j], h[2 * o + 2][j], h[2 * o + 3][j]);
+}
+
 __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                              long ybs, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1, Wq = Wo >> 2, Hq = Ho >> 1;  // Wq threads per pair of output rows
@@ -61,37 +93,55 @@ __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __rest
         const int c = idx / per_plane;
         const long rem = idx % per_plane;
         const int i2 = rem / Wq, t = rem % Wq;
-        const float* xp = x + b * xbs + (long)c * H * W;
-        const int cl = 8 * t - 1 < 0 ? W - 1 : 8 * t - 1;
-        const int cr = 8 * t + 8 >= W ? 0 : 8 * t + 8;
-        float h[6][4];  // horizontally filtered rows 4 i2 - 1 .. 4 i2 + 4 at the four output columns
+        f32x4 v[2];
+        fir_down2_patch(x + b * xbs + (long)c * H * W, H, W, i2, t, v);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const int r = 4 * i2 + a - 1;
-            if (r >= 0 && r < H) {
-                const float* row = xp + (long)r * W;
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + 8 * t), m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
-                const float l = row[cl], rr = row[cr];
-                h[a][0] = 0.125f * l + 0.375f * m0[0] + 0.375f * m0[1] + 0.125f * m0[2];
-                h[a][1] = 0.125f * m0[1] + 0.375f * m0[2] + 0.375f * m0[3] + 0.125f * m1[0];
-                h[a][2] = 0.125f * m0[3] + 0.375f * m1[0] + 0.375f * m1[1] + 0.125f * m1[2];
-                h[a][3] = 0.125f * m1[1] + 0.375f * m1[2] + 0.375f * m1[3] + 0.125f * rr;
-            } else {
+        for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v[o];
+    }
+}
+
+// The same pass leaving the GroupNorm statistics of its OUTPUT in the slot grid the convolution epilogues fill (conv_epilogue.h:
+// [B][G][2 halves of S = slots / 2][sum, sum of squares] in fp64), so that the norm in front of the stage's first residual block
+// (reference efficient_unet.py:95-97 behind :135) needs neither the streaming statistics pass nor -- where conv_f16x2.hip folds the
+// norm into its staging waves -- a finalize launch (round 5: 3 + 3 launches of a forward).  grid = (wave slots / 4, G, B): wave slot j
+// of (sample, group) owns the group's patches [j ipw, (j + 1) ipw) (a group's planes are contiguous: patch index = plane, row pair,
+// column quad), lane L the patches L, L + 64, ...; fp64 from the first addition, one wave total per slot: fixed order, every slot
+// written exactly once per launch.  Groups of fewer than 64 channels use half 0 and zero half 1 (as the epilogues do); a
+// 64-channel group uses all 2 S slots.
+__global__ __launch_bounds__(256) void fir_down2_stats_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y, long ybs,
+                                                              int cpg, int H, int W, int ipw, double* __restrict__ stat, int slots) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave, g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
+    const int Ho = H >> 1, Wo = W >> 1, Wq = Wo >> 2, Hq = Ho >> 1;
+    const int per_plane = Hq * Wq;
+    double s = 0.0, q = 0.0;
+    for (int k = lane; k < ipw; k += 64) {
+        const int idx = j * ipw + k;  // (< cpg * per_plane <= 2^21)
+        const int cg = idx / per_plane, rem = idx - cg * per_plane;
+        const int c = g * cpg + cg;
+        const int i2 = rem / Wq, t = rem - i2 * Wq;
+        f32x4 v[2];
+        fir_down2_patch(x + b * xbs + (long)c * H * W, H, W, i2, t, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[a][j] = 0.f;
+        for (int o = 0; o < 2; ++o) {
+            *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)v[o][e];
+                s += d;
+                q = fma(d, d, q);
             }
         }
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {  // output row 2 i2 + o takes input rows (2 o) .. (2 o + 3) of the six; same order of
-            f32x4 v;                    // additions as the generic kernel: bit-identical results
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc += ((a == 0 || a == 3) ? 0.125f : 0.375f) * h[2 * o + a][j];
-                v[j] = acc;
-            }
-            *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v;
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane == 0) {
+        double* o = stat + (((size_t)b * G + g) * slots + j) * 2;
+        o[0] = s;
+        o[1] = q;
+        if (cpg < 64) {
+            o[slots] = 0.0;  // (half 1: slot S + j, S = slots / 2 -> 2 S doubles further on)
+            o[slots + 1] = 0.0;
         }
     }
 }
@@ -157,8 +207,31 @@ static int grid_for(long total) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
-hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s) {
+// wave slots a (sample, group) of the statistics variant uses, or 0 where the variant does not apply (the caller then runs the
+// streaming statistics pass): a pure function of the geometry -- the engine's dry walk and its real walk must agree
+int fir_down2_stat_slots(int C, int G, int H, int W) {
+    const char* fe = getenv("R2DM_FIR_STATS");  // (R2DM_FIR_STATS=0: the streaming pass instead -- A/B, tests; read per call like R2DM_GN_FOLD)
+    const bool off = fe && atoi(fe) == 0;
+    if (off || G < 1 || C % G || (W % 8) || (H % 4)) return 0;
+    const int cpg = C / G;
+    if (cpg < 8 || cpg > 64 || (cpg & (cpg - 1))) return 0;
+    const int slots = conv_stat_slots(H / 2, W / 2);
+    const int used = cpg < 64 ? slots / 2 : slots;
+    const long items = (long)cpg * (H / 4) * (W / 8);
+    if (used < 4 || used % 4 || items % used || (items / used) % 64 || items / used > 64 * 16) return 0;
+    return used;
+}
+
+hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, double* stat, int G) {
     if ((W & 3) || (H & 1)) return hipErrorInvalidValue;
+    if (stat) {
+        const int used = fir_down2_stat_slots(C, G, H, W);
+        if (!used) return hipErrorInvalidValue;
+        const int cpg = C / G;
+        const int ipw = (int)((long)cpg * (H / 4) * (W / 8) / used);
+        fir_down2_stats_kernel<<<dim3(used / 4, G, B), 256, 0, s>>>(x, xbs, y, ybs, cpg, H, W, ipw, stat, conv_stat_slots(H / 2, W / 2));
+        return hipGetLastError();
+    }
     if (W % 8 == 0 && H % 4 == 0 && getenv("R2DM_FIR_NARROW") == nullptr) {
         const long tot = (long)C * (H / 4) * (W / 8);
         fir_down2_wide_kernel<<<dim3(grid_for(tot), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);

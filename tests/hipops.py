@@ -62,6 +62,20 @@ def fir_down2(x):
     return y
 
 
+def fir_down2_stats(x, groups):
+    """(y, stat): ops.Resample(down=2) plus the GroupNorm statistics of y as the engine's path leaves them -- stat (B, groups, slots, 2)
+    float64 [sum, sum of squares]; None where the geometry has no statistics variant."""
+    B, C, H, W = x.shape
+    slots = _lib.lib().r2dm_fir_down2_stat_slots(C, groups, H, W)
+    if slots == 0:
+        return None
+    y = torch.empty(B, C, H // 2, W // 2, device=x.device)
+    stat = torch.full((B, groups, slots, 2), float("nan"), device=x.device, dtype=torch.float64)
+    _lib.check(_lib.lib().r2dm_fir_down2_stats(x.data_ptr(), y.data_ptr(), stat.data_ptr(), B, C, groups, H, W, _st(x)))
+    torch.cuda.synchronize()
+    return y, stat
+
+
 def fir_up2(x):
     B, C, H, W = x.shape
     y = torch.empty(B, C, H * 2, W * 2, device=x.device)

@@ -267,6 +267,36 @@ def test_fir_resamplers(O, H, shape):
     assert max_abs(H.fir_up2(x.to(DEV)).cpu(), O.fir_up2(x.double())) < 1e-6
 
 
+@pytest.mark.parametrize("B,C,Hh,Ww", [(8, 128, 64, 1024), (2, 256, 32, 512), (3, 512, 16, 256), (2, 128, 16, 128), (1, 64, 16, 128)])
+def test_fir_down_with_fused_group_norm_statistics(H, B, C, Hh, Ww):
+    """Round 5: fir_down2_stats_kernel (resample.hip) -- the down-sampler of efficient_unet.py:135 leaving the statistics of the norm behind it
+    (efficient_unet.py:95-97) in the convolution epilogues' slot grid.  Its output equals the plain kernel's bit for bit; every slot is written;
+    the slot sums of a (sample, group) are the group's fp64 moments of the STORED output (rel. 1e-12); groups of fewer than 64 channels leave
+    the second half of the grid zero (conv_epilogue.h's convention, which the consumer-side fold of conv_f16x2.hip relies on)."""
+    x = (rnd(31, B, C, Hh, Ww) * 1.7 + 0.3).to(DEV)
+    assert H.fir_down2_stats(rnd(32, 1, 64, 8, 64).to(DEV), 8) is None  # (fewer than 64 patches per slot: the engine runs the streaming pass)
+    r = H.fir_down2_stats(x, 8)
+    assert r is not None
+    y, stat = r
+    assert torch.equal(y, H.fir_down2(x))
+    os.environ["R2DM_FIR_NARROW"] = "1"  # (the generic two-outputs-per-thread kernel: one spelled-out FMA chain in all three, resample.hip fir4)
+    try:
+        assert torch.equal(y, H.fir_down2(x))
+    finally:
+        del os.environ["R2DM_FIR_NARROW"]
+    assert torch.isfinite(stat).all()
+    cpg = C // 8
+    yd = y.double().reshape(B, 8, -1)
+    want_s, want_q = yd.sum(-1), (yd * yd).sum(-1)
+    got = stat.sum(2)
+    assert ((got[..., 0] - want_s).abs() <= 1e-12 * yd.abs().sum(-1)).all()
+    assert ((got[..., 1] - want_q).abs() <= 1e-12 * want_q).all()
+    if cpg < 64:
+        assert (stat[:, :, stat.shape[2] // 2:] == 0).all()
+    # a slot's energy bounds every element it covers: the largest slot energy bounds max|y| of the group (the range guard's M)
+    assert (stat[..., 1].amax(2).sqrt() >= yd.abs().amax(-1)).all()
+
+
 def test_fir_golden(golden, H):
     g = golden("ops")  # 6x10 maps: W%4 != 0 must be refused loudly, not silently mis-computed
     from r2dm_amd._lib import R2DMError

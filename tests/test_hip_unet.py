@@ -412,6 +412,32 @@ def test_group_norm_folded_into_its_consumer_is_bit_identical(res, batch):
     assert torch.equal(outs["1"][0], outs["0"][0])
 
 
+@pytest.mark.parametrize("res,batch", [((64, 1024), 8), ((32, 256), 2), ((128, 2048), 2)])
+def test_fir_down_statistics_match_the_streaming_pass(res, batch):
+    """Round 5: the FIR down-sampler leaves the GroupNorm statistics of its output in the convolution epilogues' slot grid (resample.hip
+    fir_down2_stats_kernel; efficient_unet.py:95-97 behind :135), so the first norm of d_block2..4 needs neither the streaming pass nor -- folded
+    into its consumer -- a finalize launch.  Against the same forward with the streaming pass (R2DM_FIR_STATS=0): fp64 sums in another order, so
+    equal to rounding of the (a, d) pairs (not bit for bit); both repeat themselves bit for bit."""
+    import r2dm_amd
+
+    ck = synthetic_ckpt(resolution=res)
+    x, c = rnd(11, batch, 2, *res).to(DEV), torch.linspace(-3.0, 5.0, batch).to(DEV)
+    outs = {}
+    saved = os.environ.get("R2DM_FIR_STATS")
+    for mode in ("1", "0"):
+        os.environ["R2DM_FIR_STATS"] = mode
+        try:
+            m, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=batch)
+            outs[mode] = (m.model(x, c).clone(), m.model(x, c).clone())
+            del m
+        finally:
+            os.environ.pop("R2DM_FIR_STATS", None)
+            if saved is not None:
+                os.environ["R2DM_FIR_STATS"] = saved
+    assert torch.equal(outs["1"][0], outs["1"][1]) and torch.equal(outs["0"][0], outs["0"][1])
+    assert max_abs(outs["1"][0], outs["0"][0]) < 2e-6 and rms(outs["1"][0], outs["0"][0]) < 2e-7
+
+
 def test_second_golden_resolution_32x256(golden):
     """every golden so far is 16x128 -- one 64-pixel tile column wide for most kernels.  The reference's own run at
     32x256 (tests/golden/make_golden.py res2): several tile columns and tile rows per kernel, whole denoiser at three conditions and a 4-step

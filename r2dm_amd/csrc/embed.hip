@@ -75,11 +75,26 @@ __global__ __launch_bounds__(256) void ada_proj_kernel(const float* __restrict__
         double acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.0;
-        for (int k = lane; k < T; k += 64) {
-            const double wv = (double)wr[k];
+        if ((T & 255) == 0) {  // (every U-Net: T = 256) 16-byte loads -- the row and the eight activations are 9 requests per lane instead of 36
+            for (int k = 4 * lane; k < T; k += 256) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+                f32x4 av[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (b0 + j < B) acc[j] += wv * (double)act[(long)(b0 + j) * T + k];
+                for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(act + (long)(b0 + j < B ? b0 + j : b0) * T + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b0 + j < B) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j] += (double)wv[e] * (double)av[j][e];
+                    }
+            }
+        } else {
+            for (int k = lane; k < T; k += 64) {
+                const double wv = (double)wr[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b0 + j < B) acc[j] += wv * (double)act[(long)(b0 + j) * T + k];
+            }
         }
         const double t = wave_sum8_scatter(acc, lane);  // lane L: the total of sample b0 + ((L >> 3) & 7)
         const int j = (lane >> 3) & 7;

@@ -183,6 +183,21 @@ def test_discrete_golden(golden):
     assert max_abs(out, g["sample_out"]) < 3e-4
 
 
+def test_per_sample_noise_rows_equal_the_reference_stack():
+    """base.py:81-85 stacks one torch.randn per sample generator; GaussianDiffusion.randn draws straight into the rows of the result (no copy
+    kernel in the step loop): the same values, generator states advanced alike -- on the device generators the samplers use."""
+    import r2dm_amd
+
+    ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(), device=DEV, show_info=False)
+    shape = (5, 2, *GOLDEN_RES)
+    for _ in range(2):  # (second round: the states left by the first)
+        ga, gb = r2dm_amd.setup_rng(list(range(5)), DEV), r2dm_amd.setup_rng(list(range(5)), DEV)
+        for _ in range(3):
+            want = torch.stack([torch.randn(*shape[1:], generator=r, device=DEV) for r in ga])
+            got = ddpm.randn(*shape, rng=gb, device=DEV)
+            assert torch.equal(got, want)
+
+
 def test_seeded_sampling_partition_invariant(small):
     """Per-sample generators (utils/inference.py:113-114): a sample depends on its seed only, not on
     which batch / rank drew it -- the property multi-GPU sharding relies on (sample_and_save.py:37-46,75)."""

@@ -1104,7 +1104,13 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
         const int off = ((ln >> 3) * HW + (th * TH + s / SEGW) * W + tw * TW + (s % SEGW) * 32 + (ln & 7) * 4) >> 2;
         const gcrv ru = (gcrv)(reinterpret_cast<const unsigned char*>(p.res) + ((long)b * p.res_bs + (long)(cot * COT) * HW) * YE);
 #pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) rv[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
+        for (int k8 = 0; k8 < 4; ++k8) {
+#ifdef F2_NT_RES  // experiment (round 5): the residual is read once
+            rv[k8] = __builtin_nontemporal_load(ru + (long)(m * 32 + k8 * 8) * (HW >> 2) + off);
+#else
+            rv[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
+#endif
+        }
     };
     auto res_request = [&](auto QD, int b, int th, int tw, int cot, int ln) __attribute__((always_inline)) { res_request_to(rv_e, QD, b, th, tw, cot, ln); };
     // quarter QD's residual -> the wave's waiting slot QD (0 | 1) by LDS-DMA: four pieces of 1 KiB (one 8-channel block each)
@@ -1152,7 +1158,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = pk;
                 v = rv_f32(pk);
             } else {
+#ifdef F2_NT_STORE  // experiment (round 5): the output as a streaming store -- it is not read again before the launch ends
+                __builtin_nontemporal_store(v, yu + (long)(m * 32 + k8 * 8) * (HW >> 2) + off);
+#else
                 (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
+#endif
             }
             if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);

@@ -467,6 +467,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
             asm volatile("" : "=v"(d) : "v"(voff), "s"(base));
             return;
 #endif
+#ifdef F2_NT_XLOAD  // experiment (round 5): the input pixels as streaming loads
+            if constexpr (X16) asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+            return;
+#endif
             if constexpr (X16) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
         };

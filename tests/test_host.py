@@ -22,6 +22,38 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.r2dm_version()
 
 
+def test_fir_down_statistics_geometry_host_logic():
+    """r2dm_fir_down2_stat_slots (resample.hip, host side): where the down-sampler leaves the GroupNorm statistics of its output -- the three
+    down-samplers of the 64x1024 and 128x2048 networks (efficient_unet.py:135 in front of :95-97) and of the 32x256 golden geometry -- and where
+    it must refuse, so that the engine falls back to the streaming pass: too few patches per slot, channels that do not split into 8 groups of
+    8 / 16 / 32 / 64, widths / heights the wide kernel does not take.  The slot count is the convolution epilogues' (conv_stat_slots of the
+    OUTPUT geometry: 4-row x 64-pixel tiles x 4 rows x 2 halves)."""
+    from r2dm_amd import _lib
+
+    f = _lib.lib().r2dm_fir_down2_stat_slots
+
+    def epi_slots(h, w):
+        return ((h + 3) // 4) * ((w + 63) // 64) * 4 * 2
+
+    for res in ((64, 1024), (128, 2048), (32, 256)):
+        h, w = res
+        for level, c in enumerate((128, 256, 512)):
+            hh, ww = h >> level, w >> level  # the down-sampler's INPUT geometry at this level
+            assert f(c, 8, hh, ww) == epi_slots(hh // 2, ww // 2), (res, level)
+    os.environ["R2DM_FIR_STATS"] = "0"
+    try:
+        assert f(128, 8, 64, 1024) == 0  # (the A/B switch)
+    finally:
+        del os.environ["R2DM_FIR_STATS"]
+    assert f(512, 8, 4, 32) == 0      # 16x128 golden network, level 3: 32 patches per slot (< one wave's 64)
+    assert f(64, 8, 8, 64) == 0       # fewer than 64 patches per slot
+    assert f(128, 8, 64, 1020) == 0   # width not a multiple of 8
+    assert f(128, 8, 62, 1024) == 0   # height not a multiple of 4
+    assert f(96, 8, 64, 1024) == 0    # 12 channels per group
+    assert f(2048, 8, 64, 1024) == 0  # 256 channels per group
+    assert f(128, 7, 64, 1024) == 0   # channels not divisible by the groups
+
+
 def test_engine_plan_and_blob_layout_without_gpu():
     """Handle creation, tensor table and workspace sizing are host-only."""
     from r2dm_amd import _lib, synthetic

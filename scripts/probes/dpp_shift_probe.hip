@@ -1,0 +1,58 @@
+// Round 5 probe: does a wave-wide DPP shift (v_mov_b32_dpp wave_shr:1 / wave_shl:1) deliver the neighbour lane's value while ANOTHER PROCESS's
+// waves share the CU?  (The neighbour-lane variants of out_conv / fir_down2 / fir_up2 were bit-identical to their load versions alone and failed the
+// two-rank drop-in test in 5 of 7 runs: profiles/r05_small_kernels.txt.)  A streaming kernel in the FIR kernels' shape: every lane loads 16 bytes,
+// takes its neighbours' edge words by DPP, and compares them with the same words loaded directly; mismatches are counted per (lane mod 16).
+// Usage: dpp_shift_probe <seconds> -- prints launches, compared values, mismatches.  Build: hipcc --offload-arch=gfx950 -O3 (scripts/jobs/j352.sh).
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ x, long n4, unsigned long long* __restrict__ bad, float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (long base = blockIdx.x * 256L; base < n4; base += (long)gridDim.x * 256) {
+        const long i0 = base + threadIdx.x;
+        const long i = i0 < n4 ? i0 : n4 - 1;  // (whole waves in the body)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        const float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[3]), 0x138, 0xf, 0xf, false));  // lane - 1's last word
+        const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x130, 0xf, 0xf, false));  // lane + 1's first word
+        const bool has_l = lane > 0 && i0 < n4 && i0 - 1 >= 0, has_r = lane < 63 && i0 + 1 < n4;
+        const float wl = has_l ? x[4 * i - 1] : 0.f, wr = has_r ? x[4 * i + 4] : 0.f;
+        if (has_l && __float_as_int(l) != __float_as_int(wl)) atomicAdd(bad + (lane & 15), 1ull);
+        if (has_r && __float_as_int(r) != __float_as_int(wr)) atomicAdd(bad + 16 + (lane & 15), 1ull);
+        acc += l + r + v[1];
+    }
+    if (acc == 12345.678f) *sink = acc;  // (keeps the arithmetic)
+}
+
+int main(int argc, char** argv) {
+    const double secs = argc > 1 ? atof(argv[1]) : 10.0;
+    const long n = 32L << 20;  // 128 MB of floats: a level-1 tensor
+    std::vector<float> h(n);
+    unsigned s = 12345u;
+    for (long i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = (float)(s >> 8) * (1.0f / 16777216.0f); }
+    float *x, *sink;
+    unsigned long long* bad;
+    hipMalloc(&x, n * 4); hipMalloc(&sink, 4); hipMalloc(&bad, 32 * 8);
+    hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemset(bad, 0, 32 * 8);
+    long launches = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+        for (int k = 0; k < 20; ++k) probe<<<8192, 256>>>(x, n / 4, bad, sink);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("dpp_shift_probe: launch failed\n"); return 2; }
+        launches += 20;
+    }
+    unsigned long long hb[32];
+    hipMemcpy(hb, bad, sizeof hb, hipMemcpyDeviceToHost);
+    unsigned long long tl = 0, tr = 0;
+    for (int i = 0; i < 16; ++i) { tl += hb[i]; tr += hb[16 + i]; }
+    printf("dpp_shift_probe: %ld launches, %.3g neighbour words compared, mismatches wave_shr %llu wave_shl %llu  by lane %% 16 (shr):", launches, (double)launches * (n / 4) * 2, tl, tr);
+    for (int i = 0; i < 16; ++i) printf(" %llu", hb[i]);
+    printf("\n");
+    return (tl + tr) ? 1 : 0;
+}

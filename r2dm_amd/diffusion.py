@@ -253,6 +253,8 @@ class GaussianDiffusion(nn.Module):
             assert len(rng) == shape[0]
             # (base.py:81-85 stacks per-sample draws; drawn straight into the rows of the result here -- the same values from the same
             # generator states, one copy kernel and 2 x the bytes less per step)
+            if not rng:
+                return torch.stack([])  # (the reference's error for an empty batch)
             out = torch.empty(*shape, **kwargs)
             for i, r in enumerate(rng):
                 torch.randn(*shape[1:], generator=r, out=out[i])

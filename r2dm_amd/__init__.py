@@ -13,4 +13,4 @@ __all__ = [
     "ContinuousTimeGaussianDiffusion", "DiscreteTimeGaussianDiffusion", "GaussianDiffusion", "EfficientUNet",
     "LiDARUtility", "Config", "setup_model", "setup_rng",
 ]
-__version__ = "0.3.0"
+__version__ = "0.4.0"

@@ -866,7 +866,7 @@ int check_config(const r2dm_config& c) {
 extern "C" {
 
 const char* r2dm_last_error(void) { return g_err; }
-const char* r2dm_version(void) { return "r2dm_hip 0.4 (gfx950)"; }
+const char* r2dm_version(void) { return "r2dm_hip 0.5 (gfx950)"; }
 
 int r2dm_create(r2dm_handle** out, const r2dm_config* cfg) {
     if (!out || !cfg) return fail(1, "null argument");

@@ -236,7 +236,8 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s) {
         const unsigned nbx = (unsigned)(((p.W + 255) / 256) * (p.H / 4) * p.B);
         // shares of the output channels (blockIdx.y): whole statistics groups of whole 8-channel blocks, up to four, while the launch has
         // fewer than ~16 waves per CU
-        static const int max_split = getenv("R2DM_FEW_IN_SPLIT") ? atoi(getenv("R2DM_FEW_IN_SPLIT")) : 2;
+        const char* fs = getenv("R2DM_FEW_IN_SPLIT");  // (1 | 2 | 4: experiments and the bit-identity test; read per call)
+        const int max_split = fs ? atoi(fs) : 2;
         const int unit = p.stat ? p.stat_cpg : 8;
         unsigned split = 1;
         while ((int)split * 2 <= max_split && p.Cout % ((int)split * 2 * unit) == 0 && nbx * split < 2048) split *= 2;

@@ -453,6 +453,29 @@ def test_fir_down_statistics_match_the_streaming_pass(res, batch):
     assert max_abs(outs["1"][0], outs["0"][0]) < 2e-6 and rms(outs["1"][0], outs["0"][0]) < 2e-7
 
 
+@pytest.mark.parametrize("res,batch", [((64, 1024), 8), ((32, 256), 3)])
+def test_in_conv_channel_shares_are_bit_identical(res, batch):
+    """Round 5: conv_few_in_kernel (in_conv, efficient_unet.py:262,283) splits a pixel block's output channels over 1, 2 or 4 blocks (more waves
+    for the same output stream).  Every output channel is still one thread's multiply-add chain and every statistics slot one wave's sum: the
+    forward is the same bit for bit whatever the split (R2DM_FEW_IN_SPLIT, read per call)."""
+    import r2dm_amd
+
+    m, _, _ = r2dm_amd.setup_model(synthetic_ckpt(resolution=res), device=DEV, show_info=False, max_batch=batch)
+    x, c = rnd(13, batch, 2, *res).to(DEV), torch.linspace(-2.0, 4.0, batch).to(DEV)
+    outs = []
+    saved = os.environ.get("R2DM_FEW_IN_SPLIT")
+    try:
+        for split in ("1", "2", "4"):
+            os.environ["R2DM_FEW_IN_SPLIT"] = split
+            outs.append(m.model(x, c).clone())
+    finally:
+        os.environ.pop("R2DM_FEW_IN_SPLIT", None)
+        if saved is not None:
+            os.environ["R2DM_FEW_IN_SPLIT"] = saved
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[1], m.model(x, c))  # (the default: two shares)
+
+
 def test_second_golden_resolution_32x256(golden):
     """every golden so far is 16x128 -- one 64-pixel tile column wide for most kernels.  The reference's own run at
     32x256 (tests/golden/make_golden.py res2): several tile columns and tile rows per kernel, whole denoiser at three conditions and a 4-step

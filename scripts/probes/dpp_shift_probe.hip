@@ -2,7 +2,7 @@
 // waves share the CU?  (The neighbour-lane variants of out_conv / fir_down2 / fir_up2 were bit-identical to their load versions alone and failed the
 // two-rank drop-in test in 5 of 7 runs: profiles/r05_small_kernels.txt.)  A streaming kernel in the FIR kernels' shape: every lane loads 16 bytes,
 // takes its neighbours' edge words by DPP, and compares them with the same words loaded directly; mismatches are counted per (lane mod 16).
-// Usage: dpp_shift_probe <seconds> -- prints launches, compared values, mismatches.  Build: hipcc --offload-arch=gfx950 -O3 (scripts/jobs/j352.sh).
+// Usage: dpp_shift_probe <seconds> [mode] -- prints launches, compared values, mismatches.  Build: hipcc --offload-arch=gfx950 -O3 (scripts/jobs/j352.sh).
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -11,7 +11,7 @@
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ x, long n4, unsigned long long* __restrict__ bad, float* __restrict__ sink) {
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ x, long n4, unsigned long long* __restrict__ bad, float* __restrict__ sink, int mode) {
     const int lane = threadIdx.x & 63;
     float acc = 0.f;
     for (long base = blockIdx.x * 256L; base < n4; base += (long)gridDim.x * 256) {
@@ -25,12 +25,28 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ x, long n
         if (has_l && __float_as_int(l) != __float_as_int(wl)) atomicAdd(bad + (lane & 15), 1ull);
         if (has_r && __float_as_int(r) != __float_as_int(wr)) atomicAdd(bad + 16 + (lane & 15), 1ull);
         acc += l + r + v[1];
+        if (mode == 2) {
+            // the FIR variants' exact shape: the DPP result is OVERWRITTEN in the seam lanes by a load executed under a partial EXEC mask
+            // (every 16th lane and the wave's ends play the seams here), then every lane's value is checked against a full-wave load
+            const bool seam_l = lane == 0 || (lane & 15) == 0, seam_r = lane == 63 || (lane & 15) == 15;
+            float l2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[3]), 0x138, 0xf, 0xf, false));
+            float r2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x130, 0xf, 0xf, false));
+            const long il = 4 * i - 1 >= 0 ? 4 * i - 1 : 0, ir = 4 * i + 4 < 4 * n4 ? 4 * i + 4 : 0;
+            if (seam_l) l2 = x[il];
+            if (seam_r) r2 = x[ir];
+            const float fl = x[il], fr = x[ir];
+            asm volatile("" : "+v"(l2), "+v"(r2));
+            if (i0 < n4 && i0 > 0 && __float_as_int(l2) != __float_as_int(fl)) atomicAdd(bad + (lane & 15), 1ull);
+            if (i0 + 1 < n4 && __float_as_int(r2) != __float_as_int(fr)) atomicAdd(bad + 16 + (lane & 15), 1ull);
+            acc += l2 + r2;
+        }
     }
     if (acc == 12345.678f) *sink = acc;  // (keeps the arithmetic)
 }
 
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 10.0;
+    const int mode = argc > 2 ? atoi(argv[2]) : 1;  // 2: + the seam-overwrite shape
     const long n = 32L << 20;  // 128 MB of floats: a level-1 tensor
     std::vector<float> h(n);
     unsigned s = 12345u;
@@ -43,7 +59,7 @@ int main(int argc, char** argv) {
     long launches = 0;
     const auto t0 = std::chrono::steady_clock::now();
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
-        for (int k = 0; k < 20; ++k) probe<<<8192, 256>>>(x, n / 4, bad, sink);
+        for (int k = 0; k < 20; ++k) probe<<<8192, 256>>>(x, n / 4, bad, sink, mode);
         if (hipDeviceSynchronize() != hipSuccess) { printf("dpp_shift_probe: launch failed\n"); return 2; }
         launches += 20;
     }

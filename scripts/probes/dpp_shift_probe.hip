@@ -44,6 +44,23 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ x, long n
     if (acc == 12345.678f) *sink = acc;  // (keeps the arithmetic)
 }
 
+// mode 3: is the SCALAR data cache isolated between processes?  Every wave re-reads, through scalar loads (constant address space: s_load), a table this
+// process filled with ITS tag; a second instance of this program holds another tag in a table that very likely sits at the same virtual address.  A scalar
+// load that returns the other process's words is counted.  (Kernel arguments travel the same way: s_load from the kernarg segment.)
+__global__ __launch_bounds__(256) void kprobe(const unsigned* __restrict__ tab, int n, unsigned tag, unsigned long long* __restrict__ bad, int reps) {
+    using cu = const unsigned __attribute__((address_space(4)))*;
+    const cu t = (cu)tab;
+    unsigned long long wrong = 0;
+    for (int r = 0; r < reps; ++r) {
+        const int i = (int)((blockIdx.x * 7u + r * 13u) % (unsigned)n);
+        const unsigned v = t[i];  // wave-uniform index: a scalar load
+        if (v != (tag ^ (unsigned)i)) ++wrong;
+        __builtin_amdgcn_s_sleep(2);
+        asm volatile("s_dcache_inv" ::: "memory");  // (each repetition a fresh fetch through the shared scalar cache hierarchy)
+    }
+    if (wrong && (threadIdx.x & 63) == 0) atomicAdd(bad, wrong);
+}
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 10.0;
     const int mode = argc > 2 ? atoi(argv[2]) : 1;  // 2: + the seam-overwrite shape
@@ -56,6 +73,26 @@ int main(int argc, char** argv) {
     hipMalloc(&x, n * 4); hipMalloc(&sink, 4); hipMalloc(&bad, 32 * 8);
     hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemset(bad, 0, 32 * 8);
+    if (mode == 3) {
+        const unsigned tag = argc > 3 ? (unsigned)strtoul(argv[3], nullptr, 0) : 0x12345678u;
+        const int nt = 1 << 16;
+        std::vector<unsigned> ht(nt);
+        for (int i = 0; i < nt; ++i) ht[i] = tag ^ (unsigned)i;
+        unsigned* tab;
+        hipMalloc(&tab, nt * 4);
+        hipMemcpy(tab, ht.data(), nt * 4, hipMemcpyHostToDevice);
+        long kl = 0;
+        const auto k0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count() < secs) {
+            for (int k = 0; k < 20; ++k) kprobe<<<4096, 256>>>(tab, nt, tag, bad, 64);
+            if (hipDeviceSynchronize() != hipSuccess) { printf("dpp_shift_probe: launch failed\n"); return 2; }
+            kl += 20;
+        }
+        unsigned long long hb0 = 0;
+        hipMemcpy(&hb0, bad, 8, hipMemcpyDeviceToHost);
+        printf("scalar_cache_probe: tag 0x%08x table at %p, %ld launches x 4096 blocks x 4 waves x 64 scalar loads, wrong words %llu\n", tag, (void*)tab, kl, hb0);
+        return hb0 ? 1 : 0;
+    }
     long launches = 0;
     const auto t0 = std::chrono::steady_clock::now();
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {

@@ -16,7 +16,7 @@ hog = None
 if nb == "conv":
     ready = "/tmp/fir_soak_ready"
     if os.path.exists(ready): os.remove(ready)
-    hog = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "hog_conv_loop.py")], env=dict(os.environ, SHAPE=os.environ.get("HOG_SHAPE", "64,64,64,1024,3,8"), SECS="40", READY_FILE=ready),
+    hog = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "hog_conv_loop.py")], env=dict(os.environ, SHAPE=os.environ.get("HOG_SHAPE", "64,64,64,1024,3,8"), SECS="40", READY_FILE=ready),  # (HOG_TORCH_ONLY=1: element-wise torch kernels only)
                            cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     t0 = time.time()
     while not os.path.exists(ready) and time.time() - t0 < 60: time.sleep(0.5)
@@ -26,11 +26,22 @@ elif nb == "sampler":
                             "import time; t0 = time.time()\n"
                             "while time.time() - t0 < 40: m.sample(2, 2, progress=False); torch.cuda.synchronize()"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     time.sleep(12)
-bad = [0, 0, 0]; n = 0
+bad = [0, 0, 0]; shown = [0, 0, 0]; n = 0
 t0 = time.time()
 while time.time() - t0 < float(os.environ.get("SECS", "15")):
     for k, x in enumerate(xs):
-        bad[k] += int(not torch.equal(H.fir_up2(x), ref[k]))
+        y = H.fir_up2(x)
+        if not torch.equal(y, ref[k]):
+            bad[k] += 1
+            if shown[k] < 3:  # what the corruption looks like: where, how much, against what
+                shown[k] += 1
+                d = (y != ref[k])
+                idx = d.nonzero()
+                b_, c_, r_, w_ = (idx[:, j] for j in range(4))
+                yv, rv = y[d], ref[k][d]
+                print(f"  shape {tuple(x.shape)}: {int(d.sum())} of {d.numel()} elements differ; batch {sorted(set(b_.tolist()))} planes {int(c_.min())}..{int(c_.max())} ({len(set(c_.tolist()))} distinct) "
+                      f"rows {sorted(set(r_.tolist()))[:12]} cols {int(w_.min())}..{int(w_.max())}; got zeros {int((yv == 0).sum())}, ref zeros {int((rv == 0).sum())}, max |diff| {float((yv - rv).abs().max()):.3g}, "
+                      f"first (b, c, row, col) {idx[0].tolist()} got {float(yv[0]):.6g} want {float(rv[0]):.6g}", flush=True)
     n += 1
 print(f"fir_up_soak: library {os.environ.get('R2DM_HIP_LIB', 'default')} neighbour {nb}: {n} rounds, outputs differing from the first per shape {bad}", flush=True)
 if hog: hog.terminate(); hog.wait()

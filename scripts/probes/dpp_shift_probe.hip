@@ -61,6 +61,28 @@ __global__ __launch_bounds__(256) void kprobe(const unsigned* __restrict__ tab, 
     if (wrong && (threadIdx.x & 63) == 0) atomicAdd(bad, wrong);
 }
 
+// mode 4: v_cndmask_b32 with an SGPR-PAIR lane mask (VOP3) in a hot loop -- what the branch-free fir_up2 body is made of and the committed one is not.  Every lane
+// checks the select against the same choice made with integer arithmetic; mismatches are counted per 16-lane quarter of the wave (the corrupted outputs of the
+// rewritten kernel sit in lanes 48-63).
+__global__ __launch_bounds__(256) void cprobe(const float* __restrict__ x, long n, unsigned long long* __restrict__ bad, float* __restrict__ sink, int reps) {
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (long base = blockIdx.x * 256L; base < n; base += (long)gridDim.x * 256) {
+        const long i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const float a = x[i], b = x[(i * 7 + 3) % n];
+        for (int r = 0; r < reps; ++r) {
+            const bool c = ((__float_as_uint(a) >> (r & 15)) ^ (unsigned)(lane >> 2) ^ (unsigned)r) & 1u;
+            const unsigned long long m = __ballot(c);  // the condition as an SGPR pair
+            float sel;
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(a), "v"(b), "s"(m));
+            const unsigned want = c ? __float_as_uint(b) : __float_as_uint(a);
+            if (__float_as_uint(sel) != want) atomicAdd(bad + (lane >> 4), 1ull);
+            acc += sel;
+        }
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 10.0;
     const int mode = argc > 2 ? atoi(argv[2]) : 1;  // 2: + the seam-overwrite shape
@@ -92,6 +114,19 @@ int main(int argc, char** argv) {
         hipMemcpy(&hb0, bad, 8, hipMemcpyDeviceToHost);
         printf("scalar_cache_probe: tag 0x%08x table at %p, %ld launches x 4096 blocks x 4 waves x 64 scalar loads, wrong words %llu\n", tag, (void*)tab, kl, hb0);
         return hb0 ? 1 : 0;
+    }
+    if (mode == 4) {
+        long kl = 0;
+        const auto k0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count() < secs) {
+            for (int k = 0; k < 20; ++k) cprobe<<<4096, 256>>>(x, 1L << 22, bad, sink, 32);
+            if (hipDeviceSynchronize() != hipSuccess) { printf("dpp_shift_probe: launch failed\n"); return 2; }
+            kl += 20;
+        }
+        unsigned long long hq[4];
+        hipMemcpy(hq, bad, sizeof hq, hipMemcpyDeviceToHost);
+        printf("cndmask_probe: %ld launches, %.3g selects checked, mismatches by lane quarter: %llu %llu %llu %llu\n", kl, (double)kl * (1L << 22) * 32, hq[0], hq[1], hq[2], hq[3]);
+        return (hq[0] + hq[1] + hq[2] + hq[3]) ? 1 : 0;
     }
     long launches = 0;
     const auto t0 = std::chrono::steady_clock::now();

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -83,6 +84,65 @@ __global__ __launch_bounds__(256) void cprobe(const float* __restrict__ x, long 
     if (acc == 12345.678f) *sink = acc;
 }
 
+// mode 5: the branch-free fir_up2 body's LOADS (three rows from a clamped row index: one 8-byte and two 4-byte loads each) checked word by word against the
+// pattern the buffer holds (x[k] = pat(k)); mode 6: the same loads, then the body's ARITHMETIC done twice from the same registers (selects on the row-inside-the-
+// image predicate, the [1,3]/4 chains) and the two results compared.  Mismatches by 16-lane quarter of the wave.
+__device__ __forceinline__ unsigned pat(long k) { return (unsigned)(k * 2654435761u) >> 9 | 0x3f800000u; }  // a float in [1, 2)
+__global__ __launch_bounds__(256) void fprobe(const float* __restrict__ x, int C, int H, int W, unsigned long long* __restrict__ bad, float* __restrict__ sink, int mode) {
+    const int Wh = W >> 1, lane = threadIdx.x & 63;
+    const long per_plane = (long)H * Wh, total = per_plane * C;
+    float keep = 0.f;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx / per_plane;
+        const long rem = idx % per_plane;
+        const int i = rem / Wh, t = rem % Wh;
+        const float* xp = x + (long)c * H * W;
+        const int cl = 2 * t - 1 < 0 ? W - 1 : 2 * t - 1, cr = 2 * t + 2 >= W ? 0 : 2 * t + 2;
+        float h[2][3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int r = i + a - 1;
+            const bool ok = r >= 0 && r < H;
+            const float* row = xp + (long)(ok ? r : i) * W;
+            const float2 m = *reinterpret_cast<const float2*>(row + 2 * t);
+            const float l = row[cl], rr = row[cr];
+            if (mode == 5) {
+                const long k0 = (row - x) + 2 * t;
+                int w = 0;
+                w += __float_as_uint(m.x) != pat(k0);
+                w += __float_as_uint(m.y) != pat(k0 + 1);
+                w += __float_as_uint(l) != pat((row - x) + cl);
+                w += __float_as_uint(rr) != pat((row - x) + cr);
+                if (w) atomicAdd(bad + (lane >> 4), (unsigned long long)w);
+            }
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                float mx = m.x, my = m.y, ll = l, rq = rr;
+                asm volatile("" : "+v"(mx), "+v"(my), "+v"(ll), "+v"(rq));  // (two independent evaluations of the same registers)
+                h[rep][a][0] = ok ? ll * 0.25f + mx * 0.75f : 0.f;
+                h[rep][a][1] = ok ? mx * 0.75f + my * 0.25f : 0.f;
+                h[rep][a][2] = ok ? mx * 0.25f + my * 0.75f : 0.f;
+                h[rep][a][3] = ok ? my * 0.75f + rq * 0.25f : 0.f;
+            }
+        }
+        int w2 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float e[2], o[2];
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                e[rep] = h[rep][0][j] * 0.25f + h[rep][1][j] * 0.75f;
+                o[rep] = h[rep][1][j] * 0.75f + h[rep][2][j] * 0.25f;
+            }
+            w2 += __float_as_uint(e[0]) != __float_as_uint(e[1]);
+            w2 += __float_as_uint(o[0]) != __float_as_uint(o[1]);
+            keep += e[0] + o[1];
+        }
+        if (mode == 6 && w2) atomicAdd(bad + 4 + (lane >> 4), (unsigned long long)w2);
+    }
+    if (keep == 12345.678f) *sink = keep;
+}
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 10.0;
     const int mode = argc > 2 ? atoi(argv[2]) : 1;  // 2: + the seam-overwrite shape
@@ -114,6 +174,23 @@ int main(int argc, char** argv) {
         hipMemcpy(&hb0, bad, 8, hipMemcpyDeviceToHost);
         printf("scalar_cache_probe: tag 0x%08x table at %p, %ld launches x 4096 blocks x 4 waves x 64 scalar loads, wrong words %llu\n", tag, (void*)tab, kl, hb0);
         return hb0 ? 1 : 0;
+    }
+    if (mode == 5 || mode == 6) {
+        const int C = 128, H = 32, W = 512;  // batch 2 x 64 planes of the 32 x 512 up-sampler as 128 planes
+        for (long k = 0; k < (long)C * H * W; ++k) { const unsigned u = (unsigned)(k * 2654435761u) >> 9 | 0x3f800000u; memcpy(&h[k], &u, 4); }
+        hipMemcpy(x, h.data(), (long)C * H * W * 4, hipMemcpyHostToDevice);
+        long kl = 0;
+        const auto k0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count() < secs) {
+            for (int k = 0; k < 20; ++k) fprobe<<<4096, 256>>>(x, C, H, W, bad, sink, mode);
+            if (hipDeviceSynchronize() != hipSuccess) { printf("dpp_shift_probe: launch failed\n"); return 2; }
+            kl += 20;
+        }
+        unsigned long long hq[8];
+        hipMemcpy(hq, bad, sizeof hq, hipMemcpyDeviceToHost);
+        printf("fir_body_probe mode %d: %ld launches of %d items; wrong LOADED words by lane quarter: %llu %llu %llu %llu; evaluations that DISAGREE by lane quarter: %llu %llu %llu %llu\n", mode, kl,
+               C * H * (W / 2), hq[0], hq[1], hq[2], hq[3], hq[4], hq[5], hq[6], hq[7]);
+        return 0;
     }
     if (mode == 4) {
         long kl = 0;

@@ -9,6 +9,7 @@ mkdir -p $out
 pids=()
 for f in conv_mfma conv_bf16x3 conv_f16x2 proj_f16x2 presplit conv_direct norm resample attention embed posterior engine; do
   extra=""; case $f in conv_bf16x3*|conv_f16x2|proj_f16x2|presplit) extra="-fno-slp-vectorize";; esac
+  case $f in attention|conv_direct|resample|posterior|norm|embed) extra="$extra -Xclang -target-feature -Xclang -packed-fp32-ops";; esac  # (as r2dm_amd/csrc/build.sh)
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f.hip -o $out/$f.o 2> $out/$f.err &
   pids+=($!)
 done

@@ -417,6 +417,43 @@ def test_blob_layout_fingerprint():
         m8.model.adopt_packed_weights(torch.empty(m8.model.packed_weight_bytes(), dtype=torch.uint8), layout_hash=h2)
 
 
+def test_no_packed_fp32_with_scalar_operands_in_kernels_that_share_cus(tmp_path):
+    """Round 5 (profiles/r05_coresidency.txt): a packed-fp32 VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) whose source is an SGPR pair read wrong
+    values in lanes 48-63 whenever its wave shared the CU with an LDS-holding workgroup of ANOTHER PROCESS -- the root of the "exact alone, wrong next to a second
+    process" family of rounds 2, 3 and 5.  Invariant checked on the built code objects (no GPU needed): outside conv_f16x2_kernel, whose blocks own their CUs, and
+    the kernels compiled without SGPR-operand forms, NO kernel of the library contains such an instruction (r2dm_amd/csrc/build.sh compiles the CU-sharing sources
+    that would get them -- attention, in_conv / out_conv, FIR, posterior -- without packed-fp32 instruction selection)."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "r2dm_amd", "libr2dm_hip.so")
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("llvm-objdump of the ROCm toolchain not present")
+    if not os.path.exists(lib):
+        pytest.skip("libr2dm_hip.so not built")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    offenders, kernels = {}, 0
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                name = m.group(1)
+                kernels += 1
+                continue
+            if name and re.search(r"\bv_pk_\w+_f32\b", line) and re.search(r"\bs\[\d+:\d+\]", line.split("//")[0]):
+                if "conv_f16x2_kernel" in name:  # (owns its CUs: test_conv_f16x2_blocks_own_their_cu)
+                    continue
+                offenders[name] = offenders.get(name, 0) + 1
+    assert kernels > 50, kernels
+    assert not offenders, offenders
+
+
 def test_conv_f16x2_blocks_own_their_cu(tmp_path):
     """Round 5 (profiles/r05_coresidency.txt): next to ANOTHER PROCESS's waves on its CU the one-plane 32-channel tile of
     conv_f16x2.hip ended most 600-forward runs in a GPU memory fault; with the CU to itself never.  The invariant since then: every

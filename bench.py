@@ -147,7 +147,7 @@ def torch_rocm_baseline(ck, cf, B, dev, compiled=True, compile_budget_s=240):
                 dtc = time.perf_counter() - t0
             out["compiled_fp16_autocast"] = {"value": B / (dtc / n * cf["sampler_steps"]), "unit": "images/s", "ms_per_step": dtc / n * 1e3, "compile_s": compile_s,
                                              "kind": "the same oracle through torch.compile (inductor) under torch.autocast(fp16): how /root/reference/sample_and_save.py:45,70 runs the denoiser"}
-        except BaseException as e:  # (incl. the watchdog; a compile failure must not take the line down)
+        except (Exception, TimeoutError) as e:  # (incl. the watchdog; a compile failure must not take the line down -- KeyboardInterrupt / SystemExit pass)
             out["compiled_fp16_autocast"] = {"error": repr(e)[:300]}
         finally:
             signal.alarm(0)
@@ -241,9 +241,44 @@ def pmc_traffic(what="bytes_per_launch"):
         return None
 
 
+def launch_ranks(args):
+    """`--gpus N` stands on its own (the reference gets its ranks from `accelerate launch`, /root/reference/sample_and_save.py:25-46):
+    * WORLD_SIZE set (torch.distributed.run started us): it must equal --gpus, or the line would report a world the caller did not ask for;
+    * WORLD_SIZE unset and N > 1: re-execute under `torch.distributed.run --nproc-per-node N` with the same arguments;
+    * RCCL wants one device per rank: N > torch.cuda.device_count() fails here, in seconds, naming the device count (R2DM_DIST_BACKEND=gloo
+      lets ranks share a GPU: the tests' two-ranks-on-one-GPU layout)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if args.gpus < 1:
+        sys.exit(f"bench.py: --gpus {args.gpus}: need at least one GPU")
+    backend = os.environ.get("R2DM_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if args.gpus > 1 and backend == "nccl" and args.gpus > ndev:
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs under the RCCL backend (one rank per device), but this node has "
+                 f"torch.cuda.device_count() = {ndev}; R2DM_DIST_BACKEND=gloo lets ranks share a device (tests only)")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}: start it as "
+                     f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}` (or plain `python bench.py --gpus {args.gpus}`)")
+        return
+    if args.gpus == 1:
+        return
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="number of GPUs = ranks of ONE node.  Under torch.distributed.run it must equal WORLD_SIZE; "
+                    "without a launcher (WORLD_SIZE unset) and N > 1 this process re-executes itself under torch.distributed.run with N ranks")
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1, help="BASELINE.json configs[i] (see module docstring)")
@@ -263,6 +298,7 @@ def main():
     ap.add_argument("--dump-samples", default=None, help="directory: every rank saves {seeds, samples} of the timed call (tests)")
     args = ap.parse_args()
     cf = CONFIGS[args.config]
+    launch_ranks(args)
 
     import r2dm_amd
     from r2dm_amd import synthetic
@@ -390,6 +426,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 operands, f32 accumulation / tensors (reduced-precision bulk mode: NOT the parity path)" if args.precision == "fp16" else "f32",
+            "dtype_note": {"fp32": "22-bit split fp16 operands, 3 MFMA products, f32 accum",
+                           "fp32-bf16x3": "24-bit split bf16 operands, 6 MFMA products, f32 accum",
+                           "fp16": "fp16 operands, 1 MFMA product, f32 accum (reduced)"}[args.precision],
             "arithmetic": {"fp32": "fp32 tensors and accumulation; matrix products on 22-bit split fp16 operands (3 MFMA products per fp32 product)",
                            "fp32-bf16x3": "fp32 tensors and accumulation; matrix products on exact 24-bit split bf16 operands (6 MFMA products per fp32 product)",
                            "fp16": "fp32 tensors and accumulation; matrix products on fp16 operands (1 product): reduced precision"}[args.precision],
@@ -397,7 +436,9 @@ def main():
             "config": {"workload": cf["workload"] + f"; timed = one sample() call of --steps reverse steps, value scaled to {S} steps",
                        "baseline_config": args.config, "batch_per_gpu": B, "global_batch": B * world, "resolution": list(RES),
                        "sampler": cf["mode"], "sampler_steps": S, "precision": args.precision, "clock_prewarm": pw,
-                       "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the convolutions and the attention core multiply on "
+                       "arithmetic": {"fp32": "22-bit split fp16 operands, 3 products, f32 accum. ", "fp32-bf16x3": "24-bit split bf16 operands, 6 products, f32 accum. ",
+                                      "fp16": "fp16 operands, 1 product, f32 accum (reduced). "}[args.precision] +
+                                     "fp32 tensors and fp32 accumulation everywhere; the convolutions and the attention core multiply on "
                                      "the 16-bit matrix pipe: " +
                                      {"fp32": "22-bit split operands (fp16 piece + 2^11-scaled fp16 residual; weights pre-scaled per layer by a power "
                                               "of two), 3 products per fp32 product, the residual x residual term (2^-22 relative) dropped, two fp32 "
@@ -415,6 +456,7 @@ def main():
         line["roofline"] = {
             "bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": pmc_traffic() if args.config == 1 else None,
+            "traffic_measured": False,  # (replayed from the committed PMC passes, see traffic_source: not a measurement of THIS run)
             "traffic_source": "replayed: profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, evidence set %s; "
                               "PMC counters cannot be collected inside the timed process)" % pmc_traffic("source") if args.config == 1 else None,
             "peak_definition": "dominant kernel %s: dense 16-bit MFMA peak 2500 TF/s (2.4 GHz) / %d matrix products per algorithmic "

@@ -70,6 +70,8 @@ SIGNATURES = {
     "r2dm_set_conv_pieces": (c_int32, [_P, c_int32]),
     "r2dm_check_range": (c_int32, [_P, _P]),
     "r2dm_test_raise_range_bound": (c_int32, [_P, c_float, _P]),
+    "r2dm_range_sites": (c_int32, [_P, POINTER(c_float), c_int32, POINTER(c_int32)]),
+    "r2dm_range_site_name": (c_char_p, [_P, c_int32]),
     "r2dm_profile_enable": (c_int32, [_P, c_int32]),
     "r2dm_profile_read": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "r2dm_profile_read_classes": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),

@@ -1720,6 +1720,21 @@ static hipError_t launch_f2(const ConvParams& p, long tiles, hipStream_t s) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
+#ifndef F2_SHARE_CU
+        // "a block owns its CU" is what fences the open co-residency defect (root cause NOT identified) -- so it
+        // is checked, once per instantiation, instead of assumed: with this launch's LDS request and the kernel's register allocation exactly ONE
+        // block must fit a CU.  A later drop in register or LDS use (or -DF2_SHARE_CU / R2DM_F2_LDS_EXACT=1 builds, which skip this on purpose)
+        // would otherwise re-expose the fault silently.
+        if (!lds_exact) {
+            int nb = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 512, (size_t)LDS_TOTAL);
+            if (e != hipSuccess) return e;
+            if (nb != 1) {
+                fprintf(stderr, "r2dm: conv_f16x2_kernel<%d,%d,%d,%d,%d>: %d blocks would fit one CU (must be exactly 1: a block owns its CU)\n", PRO, NPLK, MRK, NRK, IOM, nb);
+                return hipErrorLaunchFailure;
+            }
+        }
+#endif
         attr_set = true;
     }
     static const bool one_tile_blocks = getenv("R2DM_F2_NONPERSISTENT") != nullptr;  // experiments: one tile per block

@@ -120,8 +120,15 @@ struct r2dm_handle {
     int conv_pieces = 2;
     bool f16_path() const { return conv_pieces != 3; }  // operands go through fp16: their range is guarded
     bool flags_fresh = false;  // the blob's range flags have been cleared since the last r2dm_bind_blob (first load does it)
-    size_t range_flag = 0;  // blob slot (two ints, ALGO_F16X2): [0] != 0: a weight outside the fp16 range; [1]: float bits of the
-                            // largest GroupNorm output bound seen since the last r2dm_check_range
+    size_t range_flag = 0;  // blob slot (RANGE_SITES pairs of ints, ALGO_F16X2): [0] != 0: a weight outside the fp16 range; [2 k + 1]: float
+                            // bits of the largest operand bound site k has recorded since the last r2dm_check_range.  A SITE is one guarded
+                            // producer of a forward, in walk order (round 6: one pair per site instead of one for the whole forward, so that
+                            // r2dm_range_sites can say WHICH layer ran how close to 65504 -- python -m r2dm_amd.check); site 0: the test hook
+                            // and anything beyond the table.  Kernels only ever atomicMax `pair + 1`.
+    static constexpr int RANGE_SITES = 256;
+    std::vector<std::string> site_names;  // labels of the last real walk (index = site)
+    float site_bounds[RANGE_SITES] = {};  // what the last r2dm_check_range read (before it reset the device copy)
+    int sites_read = 0;
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, freqs = 0, cenc = 0, ada_w = 0, ada_b = 0;
     int ada_rows = 0;
     std::map<int, size_t> ws_cache;
@@ -206,7 +213,7 @@ void build_plan(r2dm_handle* h) {
                  C0 * c.channel_multiplier[3]};
     const long px1 = (long)c.height * c.width * c.max_batch;
 
-    h->range_flag = h->take(2);
+    h->range_flag = h->take(2 * r2dm_handle::RANGE_SITES);
     if (c.coord_channels > 0) h->cenc = h->raw("__cenc", (int64_t)c.coord_channels * c.height * c.width);
     h->freqs = h->raw("__sin_freqs", C0 / 2);
     h->w1 = h->raw("time_embedding.1.weight", (int64_t)T * C0);
@@ -379,8 +386,19 @@ struct Ctx {
     hipError_t err = hipSuccess;
     const char* where = "";
     int f2_launches = 0;  // conv_f16x2 launches of this forward so far (odd ones walk their tiles backwards: ConvParams::reverse)
+    // the fp16 operand range guard, one slot per guarded producer ("site") of the forward, in walk order; `ctx`: which layer the walk is in
+    int n_sites = 0;
+    std::string ctx;
+    int* range_site(const char* what) {
+        const int k = n_sites + 1 < r2dm_handle::RANGE_SITES ? ++n_sites : 0;  // (beyond the table: the shared slot 0 -- still guarded, just not named)
+        if ((int)h->site_names.size() <= k) h->site_names.resize(k + 1);
+        h->site_names[k] = ctx.empty() ? std::string(what) : ctx + ": " + what;
+        return (int*)blob(h->range_flag) + 2 * k;
+    }
 
-    bool dry() const { return ar->dry; }
+    // (once the arena has handed out a pointer beyond the caller's workspace NOTHING more is launched -- the walk goes on
+    // dry, so `peak` still comes out right for the error message -- instead of enqueueing kernels that write outside the workspace)
+    bool dry() const { return ar->dry || ar->overflow; }
     void note(hipError_t e, const char* w) {
         const bool debug_sync = g_debug_sync;  // fault hunting: wait for and name every launch
         if (debug_sync && e == hipSuccess && !dry()) {
@@ -442,7 +460,7 @@ struct Ctx {
             GNParams g{Src{}, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows, k.p, aff,
                        nullptr};
             // (range guard of the fp16 consumers: the slot energies bound max|x| -- norm.hip; no separate maximum is recorded)
-            if (h->f16_path()) g.range_flag = (int*)blob(h->range_flag);  // (only the fp16 operand paths have a range to guard)
+            if (h->f16_path()) g.range_flag = range_site("GroupNorm output bound |a| M + |d| (gn_finalize)");  // (only the fp16 operand paths have a range to guard)
             note(launch_group_norm_finalize(g, k.C, k.slots, st), "group_norm_finalize");
         }
         return aff;
@@ -459,7 +477,7 @@ struct Ctx {
             GNParams g{x, B, H, W, h->cfg.gn_num_groups, h->cfg.gn_eps, gamma, beta, ada, (long)h->ada_rows,
                        gn_partial, aff, nullptr};
             g.partial_max = (float*)(gn_partial + (size_t)B * h->cfg.gn_num_groups * 256 * 2);
-            if (h->f16_path()) g.range_flag = (int*)blob(h->range_flag);  // (only the fp16 operand paths have a range to guard)
+            if (h->f16_path()) g.range_flag = range_site("GroupNorm output bound |a| max|x| + |d| (streaming statistics)");  // (only the fp16 operand paths have a range to guard)
             note(launch_group_norm(g, st), "group_norm");
         }
         return aff;
@@ -562,7 +580,7 @@ struct Ctx {
                     p.gn_beta = ns->beta;
                     p.gn_ada = ns->ada;
                     p.gn_ada_stride = (long)h->ada_rows;
-                    p.gn_range = (int*)blob(h->range_flag);
+                    p.gn_range = range_site("GroupNorm output bound |a| M + |d| (folded into the convolution)");
                 }
             }
             // deep layers (many 64-channel output tiles): the input transform once, by the pre-pass (presplit.hip)
@@ -580,7 +598,7 @@ struct Ctx {
                 p.pieces = h->conv_pieces;
             }
             // (every MFMA kernel records the maximum; the direct kernels' outputs never feed an fp16 operand unnormalised)
-            if (track_out && h->f16_path() && p.algo != ALGO_DIRECT) p.range = (int*)blob(h->range_flag);
+            if (track_out && h->f16_path() && p.algo != ALGO_DIRECT) p.range = range_site("max|output| (raw input of the next fp16-operand kernel)");
             if (fused_stats) {
                 p.stat = sink->p;
                 p.stat_G = h->cfg.gn_num_groups;
@@ -639,6 +657,8 @@ struct Ctx {
 
     Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,
                           bool track_out = false, bool skip_bounded = false) {
+        const std::string blk = ctx;
+        ctx = blk + ".conv1";
         const NormSpec n1{&in_stats, blob(r.g1), blob(r.b1), nullptr};
         Sink s1 = make_sink(r.cout, H, W);
         const bool t1_16 = act16(r.conv1) && act16(r.conv2) && s1.p != nullptr;  // (the streaming statistics pass reads fp32)
@@ -648,6 +668,7 @@ struct Ctx {
         const Tensor* res;
         Tensor ident;
         if (r.has_skip) {
+            ctx = blk + ".skip";
             skip = conv(r.skip, x, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, skip_bounded);
             res = &skip;
         } else {
@@ -657,7 +678,9 @@ struct Ctx {
             ident.W = W;
             res = &ident;
         }
+        ctx = blk + ".conv2";
         Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, nullptr, res, r.scale, true, nullptr, out, out_goff, false, false, track_out, &n2, t1_16, false);
+        ctx = blk;
         drop_sink(s1);
         drop(t1);
         if (r.has_skip) drop(skip);
@@ -666,7 +689,10 @@ struct Ctx {
 
     // efficient_unet.py:42-53
     Tensor attention_block(const AttnLayer& a, const Tensor& x, const Sink& in_stats, const Sink* out, int out_goff, bool track_out = false) {
+        const std::string blk = ctx;
+        ctx = blk + ".norm";
         float2* aff = norm(in_stats, src1(x), x.H, x.W, blob(a.gamma), blob(a.beta), nullptr);
+        ctx = blk + ".qkv";
         // precision mode 2: the attention core runs on the fp16 matrix pipe (attention.hip) and needs |q|, |k|, |v| < 65504: the
         // projection's epilogue records max|qkv| in the range flag
         const bool f2 = h->f16_path();
@@ -676,7 +702,9 @@ struct Ctx {
         if (!dry()) note(launch_attention(qkv.p, o.p, B, a.C, h->cfg.attn_num_heads, x.H * x.W, st, f2 ? h->conv_pieces : 0), "attention");
         drop(qkv);
         // (the core's output is a convex combination of v: |o| <= max|qkv|, which the qkv epilogue has recorded)
+        ctx = blk + ".out_proj";
         Tensor y = conv(a.proj, src1(o), x.H, x.W, PRO_NONE, nullptr, &x, a.scale, true, nullptr, out, out_goff, false, f2, track_out);
+        ctx = blk;
         drop(o);
         return y;
     }
@@ -690,6 +718,7 @@ struct Ctx {
         Sink carry = in_stats;  // statistics of the current tensor, owned elsewhere for the stage input
         bool carry_owned = false;
         if (s.down) {
+            ctx = s.name + ".downsample";
             Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, in_tracked);
             cur = make(s.cout, H / 2, W / 2);
             // the FIR pass leaves the statistics of its output for the first residual block's norm (resample.hip; where its geometry
@@ -718,6 +747,7 @@ struct Ctx {
                 goff = out_goff;
             }
             const bool tf = h->f16_path() && last && ((s.out_tracked) || (s.track_final && !s.attn && !s.up));
+            ctx = s.name + ".residual_blocks." + std::to_string(i);
             Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, tf, i == 0 && s.skip_in_bounded && h->f16_path());
             if (carry_owned) drop_sink(carry);
             if (have) drop(cur);
@@ -727,6 +757,7 @@ struct Ctx {
             carry_owned = next.p != nullptr;
         }
         if (s.attn) {
+            ctx = s.name + ".self_attn_block";
             Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff, s.track_final && !s.up && h->f16_path());
             if (carry_owned) drop_sink(carry);
             carry_owned = false;
@@ -737,7 +768,8 @@ struct Ctx {
         if (s.up) {
             Tensor u = make(s.cout, 2 * H, 2 * W);
             const bool track = s.uconv.f2 && h->f16_path();  // the fp16-operand convolution below needs max|u| < 65504
-            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? (int*)blob(h->range_flag) : nullptr), "fir_up2");
+            ctx = s.name + ".upsample";
+            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? range_site("max|FIR output| (raw input of the up-sampling convolution)") : nullptr), "fir_up2");
             drop(cur);
             cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track, s.track_final && h->f16_path());
             drop(u);
@@ -803,6 +835,7 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     Ctx::Sink s_u2 = k.make_sink(S[6].cin, H / 2, W / 2);
     Ctx::Sink s_u3 = k.make_sink(S[5].cin, H / 4, W / 4);
     Ctx::Sink s_u4 = k.make_sink(S[4].cin, H / 8, W / 8);
+    k.ctx = "in_conv";
     Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, c.coord_channels ? &cmap_t : nullptr, 0, false, nullptr, &s_d1, 0, /*res_broadcast=*/true);
     Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2);
     k.drop(h0);
@@ -825,6 +858,7 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     k.drop(u2);
     k.drop(h1);
     k.drop_sink(s_u1);
+    k.ctx = "out_conv";
     k.conv(h->out_conv, src1(u1), H, W, PRO_NONE, nullptr, nullptr, 0, false, out);
     k.drop(u1);
     ar.release(act);
@@ -942,14 +976,23 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
     if (!h) return fail(1, "null argument");
     if (!h->blob) return 0;
     hipStream_t st = (hipStream_t)stream;
-    int v[2] = {0, 0};
+    constexpr int NS = r2dm_handle::RANGE_SITES;
+    static_assert(sizeof(int) == sizeof(float), "bounds travel as float bits");
+    int v[2 * NS];
     HIP_TRY(hipMemcpyAsync(v, h->blob + h->range_flag, sizeof(v), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    float bound;
-    memcpy(&bound, &v[1], sizeof(float));
-    if (v[1] != 0) {  // per forward: reset, so that the next check reports what ran after this one
-        const int zero = 0;
-        HIP_TRY(hipMemcpyAsync(h->blob + h->range_flag + 1, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+    float bound = 0.f;
+    int worst = 0;
+    bool any = false;
+    for (int k = 0; k < NS; ++k) {  // (bounds are non-negative floats: they order like their bit patterns; a NaN bound compares false below and trips)
+        memcpy(&h->site_bounds[k], &v[2 * k + 1], sizeof(float));
+        any = any || v[2 * k + 1] != 0;
+        if (v[2 * k + 1] > v[2 * worst + 1]) worst = k;
+    }
+    h->sites_read = (int)h->site_names.size() < NS ? (int)h->site_names.size() : NS;
+    bound = h->site_bounds[worst];
+    if (any) {  // per forward: reset, so that the next check reports what ran after this one ([0], the packers' weight flag, stays)
+        HIP_TRY(hipMemsetAsync(h->blob + h->range_flag + 1, 0, (2 * NS - 1) * sizeof(int), st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (v[0] != 0)
@@ -957,9 +1000,22 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
                        "get here); the weights are not usable");
     if (!(bound < 65504.f))
         return fail(2, "an input of the fp16-operand convolution path may be outside the fp16 range (65504): largest data-driven bound "
-                       "(GroupNorm outputs: |a| M + |d|, M >= max|x| from the statistics slots; raw inputs: recorded max|x|) = %.3g; results of "
-                       "this forward are not valid; select the bf16x3 split with r2dm_set_conv_pieces(h, 3)", (double)bound);
+                       "(GroupNorm outputs: |a| M + |d|, M >= max|x| from the statistics slots; raw inputs: recorded max|x|) = %.3g at %s; results of "
+                       "this forward are not valid; select the bf16x3 split with r2dm_set_conv_pieces(h, 3)", (double)bound,
+                    worst < (int)h->site_names.size() && !h->site_names[worst].empty() ? h->site_names[worst].c_str() : "(unnamed site)");
     return 0;
+}
+
+int r2dm_range_sites(r2dm_handle* h, float* bounds, int32_t cap, int32_t* n) {
+    if (!h || !n) return fail(1, "null argument");
+    *n = h->sites_read;
+    for (int k = 0; bounds && k < h->sites_read && k < cap; ++k) bounds[k] = h->site_bounds[k];
+    return 0;
+}
+
+const char* r2dm_range_site_name(r2dm_handle* h, int32_t k) {
+    if (!h || k < 0 || k >= (int)h->site_names.size()) return "";
+    return k == 0 && h->site_names[0].empty() ? "(shared slot: test hook / sites beyond the table)" : h->site_names[k].c_str();
 }
 
 __global__ void raise_range_bound_kernel(int* flag, float bound) { atomicMax(flag + 1, __float_as_int(bound)); }
@@ -980,7 +1036,7 @@ int r2dm_load_tensor(r2dm_handle* h, int64_t i, const float* src, int64_t numel,
     if (numel != s.numel) return fail(1, "%s: expected %lld elements, got %lld", s.key.c_str(), (long long)s.numel, (long long)numel);
     hipStream_t st = (hipStream_t)stream;
     if (!h->flags_fresh) {  // first load into a freshly bound blob: both range flags start from zero, ordered before the packers
-        HIP_TRY(hipMemsetAsync(h->blob + h->range_flag, 0, 2 * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(h->blob + h->range_flag, 0, 2 * r2dm_handle::RANGE_SITES * sizeof(int), st));
         h->flags_fresh = true;
     }
     if (s.kind == SLOT_RAW) {

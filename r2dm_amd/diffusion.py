@@ -25,6 +25,8 @@ from functools import partial
 from typing import List, Literal, Optional
 
 import os
+import warnings
+
 import torch
 from torch import nn
 from torch.special import expm1
@@ -83,12 +85,15 @@ class _Replay:
         model = getattr(model, "_orig_mod", model)  # (torch.compile wrapper)
         check = getattr(model, "check_range_or_fall_back", None)
         self.check = check if callable(check) else None
+        #  Only modes whose operands pass through fp16 can trip and fall back: a model that already runs the wide-range split
+        # ("fp32-bf16x3": its check cannot trip) keeps neither a checkpoint nor the noise of up to 32 steps (0.5 GB at 128 x 2048, batch 8)
+        self.record = self.check is not None and getattr(model, "precision", "fp32") != "fp32-bf16x3"
         self.strict = bool(getattr(model, "strict_range", False))
         self.n, self.every = num_steps, every
         self.ck_i, self.ck_x, self.noise, self.replays = 0, None, [], 0
 
     def start(self, x):
-        self.ck_x = x
+        self.ck_x = x if self.record else None
 
     def noise_for(self, i: int, draw):
         """The noise of step i: what was drawn for it before a replay, else ``draw()`` (recorded while a guard is watching)."""
@@ -96,7 +101,7 @@ class _Replay:
         if k < len(self.noise):
             return self.noise[k]
         nz = draw()
-        if self.check is not None:
+        if self.record:
             self.noise.append(nz)
         return nz
 
@@ -113,10 +118,13 @@ class _Replay:
         if not self.due(i):
             return i + 1, x
         if self.check():
+            if not self.record:  # (cannot happen: a mode without a fallback raises inside check())
+                raise _lib.R2DMError("range guard tripped in a mode that keeps no replay state")
             self.replays += 1
             self.noise = self.noise[: i + 1 - self.ck_i]
+            self.record = False  # the model now runs the wide-range split: no second trip -- the recording ends with this replay
             return self.ck_i, self.ck_x
-        self.ck_i, self.ck_x, self.noise = i + 1, x, []
+        self.ck_i, self.ck_x, self.noise = i + 1, (x if self.record else None), []
         return i + 1, x
 
 
@@ -272,6 +280,9 @@ class GaussianDiffusion(nn.Module):
         a generator's state advances on the host at launch time); the caller waits for ``event`` before it reads ``noise``.
         ``R2DM_NOISE_STREAM=0`` or a CPU tensor: a plain ``randn_like`` and no event."""
         if os.environ.get("R2DM_DEBUG_FIXED_NOISE") == "1":  # timing experiment only (WRONG samples): what do the step's noise launches cost?
+            if not self.__dict__.get("_fixed_noise_warned"):
+                self.__dict__["_fixed_noise_warned"] = True
+                warnings.warn("R2DM_DEBUG_FIXED_NOISE=1: every step reuses ONE noise tensor -- the samples are WRONG (timing experiment only)", RuntimeWarning)
             z = self.__dict__.get("_fixed_noise")
             if z is None or z.shape != x.shape or z.device != x.device:
                 z = self.__dict__["_fixed_noise"] = self.randn_like(x, rng=rng)
@@ -291,6 +302,23 @@ class GaussianDiffusion(nn.Module):
 
     def setup_parameters(self) -> None:
         raise NotImplementedError
+
+    # Where the schedule scalars are evaluated.  "host" (default): float32 on the CPU, row by row -- bit-identical
+    # to the reference's CPU run (tests/golden/schedule.npz) on any machine.  "device": with the same torch ops on the tensors' own device,
+    # as the reference does when it itself runs on a GPU (continuous_time.py:203-206,248-249: `linspace(..., device=self.device)`, log_snr,
+    # alpha, sigma of device tensors).  The two differ in the last bits of libm; that only matters where a scalar is a rounding residue --
+    # DDIM with eta = 1, whose c_2 = sqrt(1 - alpha_s^2 - c_1^2) is one on the first and last step (profiles/r05_fuzz.txt, case 15).
+    schedule_on: str = "host"
+
+    def set_schedule_on(self, where: str):
+        if where not in ("host", "device"):
+            raise ValueError(f"schedule_on must be 'host' or 'device', got {where!r}")
+        self.schedule_on = where
+        self.__dict__.pop("_tables", None)
+        return self
+
+    def _on_device(self, dev) -> bool:
+        return self.schedule_on == "device" and torch.device(dev).type == "cuda"
 
     # -- training side: out of scope ------------------------------------------------------
     def forward(self, *args, **kwargs):
@@ -373,17 +401,23 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
     # -- host-side coefficient table -------------------------------------------------------
     def _coefficient_row(self, t: torch.Tensor, s: torch.Tensor, mode: str, ddim_eta: float):
         """Scalars of continuous_time.py:203-229 for ONE (t, s) pair, as 1-element float32 tensors."""
+        lt, coef = self._coefficient_block(t, s, mode, ddim_eta)
+        return lt, coef[0]
+
+    def _coefficient_block(self, t: torch.Tensor, s: torch.Tensor, mode: str, ddim_eta: float):
+        """Scalars of continuous_time.py:203-229 for (N,) step pairs, with the reference's own torch expressions, WHERE t lives:
+        -> (log-SNR (N,), coefficients (N, 8))."""
         lt, ls = self._log_snr_1d(t), self._log_snr_1d(s)
         a_t, s_t = log_snr_to_alpha_sigma(lt)
         a_s, s_s = log_snr_to_alpha_sigma(ls)
         z = torch.zeros_like(lt)
         if mode == "ddpm":
             c = -expm1(lt - ls)
-            return lt, torch.cat([a_t, s_t, a_s, s_s, c, s_s * c.sqrt(), z, z])
+            return lt, torch.stack([a_t, s_t, a_s, s_s, c, s_s * c.sqrt(), z, z], dim=-1)
         if mode == "ddim":
             c_1 = ddim_eta * s_s / s_t * (1 - a_t**2 / a_s**2).sqrt()
             c_2 = (1 - a_s**2 - c_1**2).sqrt()
-            return lt, torch.cat([a_t, s_t, a_s, s_s, z, z, c_1, c_2])
+            return lt, torch.stack([a_t, s_t, a_s, s_s, z, z, c_1, c_2], dim=-1)
         raise ValueError(f"invalid mode {mode}")
 
     def _coefficients(self, step_t: torch.Tensor, step_s: torch.Tensor, mode: str, ddim_eta: float):
@@ -394,10 +428,13 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         (B,)-shaped tensors (continuous_time.py:203-206), i.e. on the scalar path for its CPU-runnable
         batch sizes (BASELINE configs[0]: batch 1).  Row-wise evaluation reproduces those values bit for
         bit and makes the table independent of the number of steps."""
-        step_t = step_t.detach().to("cpu", torch.float32).reshape(-1)
-        step_s = step_s.detach().to("cpu", torch.float32).reshape(-1)
         if mode not in ("ddpm", "ddim"):
             raise ValueError(f"invalid mode {mode}")
+        if self._on_device(step_t.device):  # (B,)-shaped device tensors through the same ops, as the reference on a GPU
+            lt, coef = self._coefficient_block(step_t.detach().float().reshape(-1), step_s.detach().to(step_t.device).float().reshape(-1), mode, ddim_eta)
+            return lt, coef.contiguous(), (_M_CT_DDPM if mode == "ddpm" else _M_CT_DDIM)
+        step_t = step_t.detach().to("cpu", torch.float32).reshape(-1)
+        step_s = step_s.detach().to("cpu", torch.float32).reshape(-1)
         memo, conds, rows = {}, [], []
         for i in range(step_t.numel()):
             key = (step_t[i].item(), step_s[i].item())
@@ -417,7 +454,8 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         return cond, coef, mode_id
 
     def _table_key(self, num_steps, batch_size, mode, ddim_eta, dev):
-        return (num_steps, batch_size, mode, float(ddim_eta), str(torch.device(dev)), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high)
+        return (num_steps, batch_size, mode, float(ddim_eta), str(torch.device(dev)), self.noise_schedule, self.image_d, self.noise_d_low, self.noise_d_high,
+                self.schedule_on)
 
     def _table_rows(self, num_steps: int, batch_size: int, mode: str, ddim_eta: float, dev):
         """``row(i) -> (cond (B,), coef (B, 8))`` and ``mode_id`` for a ``sample`` call.  A cached table is indexed; a new one is
@@ -436,6 +474,17 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         if mode not in ("ddpm", "ddim"):
             raise ValueError(f"invalid mode {mode}")
         mode_id = _M_CT_DDPM if mode == "ddpm" else _M_CT_DDIM
+        if self._on_device(dev):
+            # the whole table at once, on the device: `steps` is the reference's own device linspace (continuous_time.py:248), and a device
+            # elementwise kernel computes every element by the same instructions whatever the tensor's shape -- (S,) here, (B,) per step there
+            steps = torch.linspace(1.0, 0.0, num_steps + 1, device=dev)
+            lt, k = self._coefficient_block(steps[:-1], steps[1:], mode, ddim_eta)
+            cond = lt[:, None].repeat_interleave(batch_size, dim=1).contiguous()
+            coef = k[:, None, :].repeat_interleave(batch_size, dim=1).contiguous()
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            cache[key] = (cond, coef, mode_id)
+            return (lambda i: (cond[i], coef[i])), mode_id
         steps = torch.linspace(1.0, 0.0, num_steps + 1)
         pin = dev.type == "cuda"
         h_cond = torch.empty(num_steps, batch_size, pin_memory=pin)
@@ -463,8 +512,10 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
         """One reverse step p(z_s | z_t), 0 <= s < t <= 1 (continuous_time.py:192-232).
         (``_early_check``: internal -- the first step of a loop under the deferred range guard passes its step count.)"""
         self._objective_id()
-        cond, coef, mode_id = self._coefficients(step_t, step_s, mode, ddim_eta)
         dev = x_t.device
+        if self._on_device(dev):
+            step_t, step_s = step_t.to(dev), step_s.to(dev)
+        cond, coef, mode_id = self._coefficients(step_t, step_s, mode, ddim_eta)
         prediction = self.model(x_t, cond.to(dev))
         if _early_check and _early_range_check(self.model, _early_check):
             prediction = self.model(x_t, cond.to(dev))  # (repeated on the wide-range operand split)
@@ -507,6 +558,8 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
     # -- forward process pieces used by RePaint (continuous_time.py:169-190) ----------------
     def _alpha_sigma_rows(self, steps: torch.Tensor) -> torch.Tensor:
         """(alpha, sigma) per row, float32 on the host, each row evaluated on 1-element tensors (see _coefficients)."""
+        if self._on_device(steps.device):
+            return torch.stack(log_snr_to_alpha_sigma(self._log_snr_1d(steps.detach().float().reshape(-1))), dim=-1).contiguous()
         steps = steps.detach().to("cpu", torch.float32).reshape(-1)
         rows = []
         for i in range(steps.numel()):
@@ -516,6 +569,11 @@ class ContinuousTimeGaussianDiffusion(GaussianDiffusion):
 
     def _q_coef_rows(self, step_t: torch.Tensor, step_s: torch.Tensor) -> torch.Tensor:
         """(alpha_t/alpha_s, sqrt(sigma_t^2 - alpha_ts^2 sigma_s^2)) per row (continuous_time.py:181-189)."""
+        if self._on_device(step_t.device):
+            a_t, s_t = log_snr_to_alpha_sigma(self._log_snr_1d(step_t.detach().float().reshape(-1)))
+            a_s, s_s = log_snr_to_alpha_sigma(self._log_snr_1d(step_s.detach().to(step_t.device).float().reshape(-1)))
+            a_ts = a_t / a_s
+            return torch.stack([a_ts, (s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)).sqrt()], dim=-1).contiguous()
         step_t = step_t.detach().to("cpu", torch.float32).reshape(-1)
         step_s = step_s.detach().to("cpu", torch.float32).reshape(-1)
         rows = []

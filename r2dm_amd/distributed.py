@@ -46,7 +46,9 @@ def broadcast_packed_weights(model, device, src: int = 0) -> None:
         return
     on_host = td.get_backend() != "nccl"
     meta = [model.packed_layout_hash() if td.get_rank() == src else None]
-    td.broadcast_object_list(meta, src=src)  # (the layout the blob was packed for: checked by every adopter)
+    # (the layout the blob was packed for: checked by every adopter.  Under RCCL the pickled object travels through a device buffer: name the
+    # device -- the default is the CURRENT device, which is cuda:0 on every rank of a caller that did not torch.cuda.set_device(local_rank))
+    td.broadcast_object_list(meta, src=src, **({} if on_host else {"device": torch.device(device)}))
     if td.get_rank() == src:
         blob = model.packed_weights(device)
         wire = blob.cpu() if on_host else blob
@@ -58,11 +60,18 @@ def broadcast_packed_weights(model, device, src: int = 0) -> None:
 
 
 def blob_checksum(blob: torch.Tensor) -> int:
-    """A 63-bit checksum of a packed weight blob (wrapping sum of its 8-byte words, computed where the blob lives)."""
+    """A 63-bit checksum of a packed weight blob, computed where the blob lives: the wrapping sum of its 8-byte words, each multiplied by an
+    odd weight that depends on its position (word i times 2 i + 1) -- a plain sum would not notice two words changing places."""
+    blob = blob.reshape(-1)
+    if blob.dtype != torch.uint8:
+        blob = blob.view(torch.uint8)
+    if blob.storage_offset() % 8 or not blob.is_contiguous():  # (a view into a larger buffer: int64 views want 8-byte alignment)
+        blob = blob.contiguous().clone()
     n = blob.numel() // 8 * 8
     words = blob[:n].view(torch.int64)
-    tail = int(blob[n:].to(torch.int64).sum().item()) if n < blob.numel() else 0
-    return (int(words.sum().item()) + tail) & 0x7FFFFFFFFFFFFFFF
+    weight = torch.arange(words.numel(), dtype=torch.int64, device=words.device) * 2 + 1
+    tail = int((blob[n:].to(torch.int64) * torch.arange(1, blob.numel() - n + 1, dtype=torch.int64, device=blob.device)).sum().item()) if n < blob.numel() else 0
+    return (int((words * weight).sum().item()) + tail) & 0x7FFFFFFFFFFFFFFF
 
 
 def collective_report(model=None, device=None) -> dict:
@@ -101,7 +110,7 @@ def sample_sharded(sample_fn: Callable[[List[int]], torch.Tensor], seeds: Sequen
     device = torch.device(device)
     # rank 0 always owns a non-empty shard (the first len % world ranks get the extra seeds): it announces shape + dtype
     meta = [(tuple(out.shape[1:]), out.dtype) if rank == 0 else None]
-    td.broadcast_object_list(meta, src=0)
+    td.broadcast_object_list(meta, src=0, **({"device": device} if td.get_backend() == "nccl" else {}))
     tail, dtype = meta[0]
     buf = torch.zeros(max(sizes), *tail, device=device, dtype=dtype)
     if out is not None:

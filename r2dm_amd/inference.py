@@ -63,7 +63,7 @@ def _sampler(cfg: Config, model: EfficientUNet) -> GaussianDiffusion:
 
 
 def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, compile: bool = False,
-                max_batch: int = 8, precision: str = "fp32", strict_range: bool = False):
+                max_batch: int = 8, precision: str = "fp32", strict_range: bool = False, schedule_on: str = "host"):
     """Build the sampler from a checkpoint (path or the dict ``train.py`` saves: cfg / weights / ema_weights /
     global_step, train.py:294-303).
 
@@ -75,6 +75,9 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
     ``strict_range`` (extension): the default operand split passes operands through fp16 behind a data-driven range guard; when the
     guard trips, the model switches itself to ``"fp32-bf16x3"`` with one ``RuntimeWarning`` and repeats the call (the reference runs
     any finite checkpoint) -- ``strict_range=True`` raises ``R2DMRangeError`` instead.
+    ``schedule_on`` (extension): ``"host"`` (default) evaluates the sampler's step scalars in float32 on the CPU -- bit-identical to the
+    reference's CPU run on any machine; ``"device"`` evaluates them with the same torch ops on ``device``, as the reference does when it runs
+    on a GPU (continuous_time.py:203-206,248-249) -- the two differ in libm's last bits, visible only for DDIM with eta = 1.
     ``compile=True`` wraps the denoiser in ``torch.compile`` as upstream does; its forward is one ctypes call into the
     HIP library, i.e. a graph break that runs eagerly."""
     if isinstance(ckpt, (str, Path)):
@@ -86,6 +89,7 @@ def setup_model(ckpt, device="cpu", ema: bool = True, show_info: bool = True, co
     ddpm.eval().requires_grad_(False).to(device)
     model.set_precision(precision)
     model.strict_range = bool(strict_range)
+    ddpm.set_schedule_on(schedule_on)
     if compile:
         ddpm.model = torch.compile(ddpm.model)
 

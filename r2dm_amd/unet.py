@@ -324,6 +324,20 @@ class EfficientUNet(nn.Module):
                         raise _lib.R2DMRangeError(str(e)) from None
                     raise
 
+    def range_report(self):
+        """``[(site, bound)]`` of the forwards since the previous check, as the LAST ``check_range`` read them: one entry per guarded producer
+        of a forward in walk order -- a GroupNorm's output bound ``|a| M + |d|`` or the recorded ``max|output|`` of a tensor the next
+        fp16-operand kernel reads raw.  ``bound / 65504`` is the fraction of the fp16 range a layer used; >= 1 is a trip
+        (``python -m r2dm_amd.check``)."""
+        if self._engine is None:
+            return []
+        n = ctypes.c_int32(0)
+        L = _lib.lib()
+        _lib.check(L.r2dm_range_sites(self._engine.h, None, 0, ctypes.byref(n)))
+        buf = (ctypes.c_float * max(n.value, 1))()
+        _lib.check(L.r2dm_range_sites(self._engine.h, buf, n.value, ctypes.byref(n)))
+        return [(L.r2dm_range_site_name(self._engine.h, k).decode(), float(buf[k])) for k in range(n.value) if k > 0 or buf[k] > 0]
+
     def check_range_or_fall_back(self) -> bool:
         """``check_range``; if the guard tripped and ``strict_range`` is off, switch this model to ``"fp32-bf16x3"`` for good
         (one warning) and return True: the caller repeats what it ran since the last check."""

@@ -113,6 +113,55 @@ def test_random_sampler_arguments_against_the_oracle():
     assert "10 cases, 0 failures" in r.stdout and r.stdout.count("Error OK") == 2, r.stdout[-3000:]
 
 
+def test_ddim_eta1_with_the_schedule_scalars_on_the_device():
+    """VERDICT round 5, missing #3 / item 6: the reference evaluates linspace, log-SNR, alpha, sigma on `self.device`
+    (/root/reference/models/diffusion/continuous_time.py:203-206,248-249); the product's default is the host (pinned to the reference's CPU
+    run).  For DDIM with eta = 1, c_2 = sqrt(1 - alpha_s^2 - c_1^2) is a rounding residue on the first and last step, and the two libms put
+    the sample 5e-4 apart (profiles/r05_fuzz.txt, case 15).  `schedule_on="device"`: (1) the table's rows ARE the oracle's device-evaluated
+    scalars, bit for bit; (2) the eta = 1 sample then meets the tight bar against the oracle that evaluates its scalars on the device."""
+    import r2dm_amd
+    from oracle import r2dm_oracle as O
+    from r2dm_amd import synthetic
+
+    dev = torch.device("cuda", 0)
+    RES, S, B, ETA = (16, 128), 4, 4, 1.0
+    ck = synthetic.synthetic_checkpoint(seed=0, resolution=RES, prediction_type="eps", noise_schedule="cosine")
+    ddpm, _, _ = r2dm_amd.setup_model(ck, device=dev, show_info=False, max_batch=8, schedule_on="device")
+    assert ddpm.schedule_on == "device"
+    # (1) the scalars: the table against the reference's expressions on (B,)-shaped device tensors, step by step
+    cond, coef, _ = ddpm._sample_tables(S, B, "ddim", ETA, dev)
+    steps = torch.linspace(1.0, 0.0, S + 1, device=dev)[None].repeat_interleave(B, dim=0)
+    for i in range(S):
+        lt, ls = O.log_snr_cosine(steps[:, i]), O.log_snr_cosine(steps[:, i + 1])
+        a_t, s_t = O.alpha_sigma(lt)
+        a_s, s_s = O.alpha_sigma(ls)
+        c1 = ETA * s_s / s_t * (1 - a_t**2 / a_s**2).sqrt()
+        c2 = (1 - a_s**2 - c1**2).sqrt()
+        assert torch.equal(cond[i], lt)
+        assert torch.equal(coef[i], torch.stack([a_t, s_t, a_s, s_s, torch.zeros_like(lt), torch.zeros_like(lt), c1, c2], dim=-1))
+    # ... and p_step's (B,)-shaped evaluation agrees with the table
+    _, krow, _ = ddpm._coefficients(steps[:, 0], steps[:, 1], "ddim", ETA)
+    assert torch.equal(krow, coef[0])
+    # (2) the sample
+    mk = lambda: r2dm_amd.setup_rng(list(range(100, 100 + B)), dev)
+    got = ddpm.sample(batch_size=B, num_steps=S, progress=False, rng=mk(), mode="ddim", ddim_eta=ETA)
+    sd = {k: v.double().to(dev) for k, v in O.strip_prefix(ck["ema_weights"]).items()}
+    cfg = O.UNetConfig(resolution=RES)
+    net = lambda x, c: O.unet_forward(sd, cfg, x.double(), c.double()).float()
+    g = mk()
+    tape = [O.draw_noise((B, 2, *RES), g, dev, torch.float32) for _ in range(S + 1)]
+    want = O.sample_continuous(net, (B, 2, *RES), S, noises=tape, mode="ddim", ddim_eta=ETA, objective="eps", device=dev)
+    e = (got - want).abs().flatten().double()
+    eq99, erms, emax = torch.quantile(e, 0.99).item(), e.pow(2).mean().sqrt().item(), e.max().item()
+    # the host-evaluated table on the same tape, for the record (the 5e-4 of the fuzz's case 15)
+    ddpm.set_schedule_on("host")
+    host = ddpm.sample(batch_size=B, num_steps=S, progress=False, rng=mk(), mode="ddim", ddim_eta=ETA)
+    print(f"DDIM eta=1: |hip(schedule on device) - oracle(device scalars)| q99 {eq99:.2e} rms {erms:.2e} max {emax:.2e}; "
+          f"hip(schedule on host) vs the same oracle: q99 {q99(host, want):.2e} rms {rms(host, want):.2e}")
+    # tight bar: what DDPM / DDIM eta < 1 meet (profiles/r05_fuzz.txt: q99 <= 5e-6, rms <= 2e-5; the max is the ill-conditioned clamp tail, DESIGN.md section 2)
+    assert eq99 < 5e-6 and erms < 2e-5 and emax < 3e-3, (eq99, erms, emax)
+
+
 def test_unsupported_channel_multiplier_is_rejected():
     """An up stage whose concatenated input equals its output width would take an identity skip over a concatenation."""
     import r2dm_amd
@@ -243,6 +292,25 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path, cfg, batch):
         two, one = torch.load(d2 / f"rank{rank}.pt"), torch.load(d1 / "rank0.pt")
         assert two["seeds"] == one["seeds"] == list(range(batch * rank, batch * rank + batch))
         assert torch.equal(two["samples"], one["samples"])
+
+
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """VERDICT round 5, item 2: `python bench.py --gpus 2` without a launcher starts two ranks itself (re-exec under torch.distributed.run);
+    under gloo they share this GPU and the line reports n_gpus 2 and a world of 2.  With the RCCL backend the same command on a one-GPU
+    box must stop in seconds with a message naming the device count (RCCL wants one device per rank)."""
+    common = ["--steps", "2", "--warmup", "1", "--batch", "1", "--no-cpu-baseline", "--no-torch-baseline", "--no-exact-baseline", "--no-other-configs", "--prewarm-s", "0.2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=dict(env, R2DM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["world_size"] == 2 and line["config"]["global_batch"] == 2
+    assert line["dtype"] == "f32" and line["dtype_note"].startswith("22-bit split fp16 operands") and line["roofline"]["traffic_measured"] is False
+    if torch.cuda.device_count() == 1:
+        import time
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=dict(env, R2DM_DIST_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "device_count() = 1" in r.stderr and time.time() - t0 < 120, r.stderr[-500:]
 
 
 _RCCL_SELFTEST = r"""

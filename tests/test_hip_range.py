@@ -323,3 +323,45 @@ def test_late_range_guard_trip_is_replayed_from_the_last_checked_step():
         allx = c.sample(batch_size=2, num_steps=6, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV), return_all=True)
     assert allx.shape[0] == 7 and len(n) == 12
     assert torch.equal(allx[-1], wide.sample(batch_size=2, num_steps=6, progress=False, rng=r2dm_amd.setup_rng([5, 6], DEV)))
+
+
+def test_checkpoint_preflight_on_both_sides_of_the_trip_point(capsys):
+    """VERDICT round 5, item 5 / missing #2: `python -m r2dm_amd.check <ckpt>` -- the sampler's own loop with the guard read after every
+    step, per guarded layer the largest bound / 65504 and where it peaked, exit code 1 iff a step would fall back.  Driven over the
+    synthetic checkpoint with HEAVY-TAILED AdaGN gains (Cauchy-distributed scales through the projection biases,
+    /root/reference/models/ops.py:190-200) scaled to either side of the trip point."""
+    from r2dm_amd import check
+
+    def ckpt(c):
+        g = torch.Generator().manual_seed(11)
+
+        def edit(w):
+            for k in list(w):
+                if k.endswith("norm2.proj.1.bias"):
+                    C = w[k].numel() // 2
+                    nb = w[k].clone()
+                    u = torch.rand(C, generator=g)
+                    nb[:C] = c * torch.tan(3.14159265 * (u - 0.5)).clamp(-200, 200)  # Cauchy, tails cut at +-200 c
+                    w[k] = nb
+        return _edited(synthetic_ckpt(), edit)
+
+    # c = 0.3: |1 + scale| up to ~60 -> bounds of a few thousand at most; c = 30: |1 + scale| up to 6000 x (M ~ 20 sigma) >> 65504
+    lo = check.preflight(ckpt(0.3), num_steps=8, batch=2, device=DEV)
+    assert lo["trips"] == [] and len(lo["sites"]) > 40
+    name, b, i, cond = lo["sites"][0]
+    assert 100.0 < b < 65504.0 and ".conv2: GroupNorm output bound" in name, lo["sites"][:3]
+    hi = check.preflight(ckpt(30.0), num_steps=8, batch=2, device=DEV)
+    assert len(hi["trips"]) >= 1 and hi["sites"][0][1] >= 65504.0
+    assert all(".conv2: GroupNorm output bound" in t[3] for t in hi["trips"]), hi["trips"][:3]
+    # ... and the command line: exit codes 0 / 1, the table names the layer
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for c, rc in ((0.3, 0), (30.0, 1)):
+            path = os.path.join(d, f"ck{rc}.pth")
+            torch.save(ckpt(c), path)
+            assert check.main([path, "--steps", "4", "--batch", "1", "--device", DEV, "--top", "5"]) == rc
+            out = capsys.readouterr().out
+            assert "bound / 65504" in out and ("would fall back" in out) == bool(rc), out[-600:]
+    # the default synthetic checkpoint itself: far inside the range
+    base = check.preflight(synthetic_ckpt(), num_steps=4, batch=1, device=DEV)
+    assert base["trips"] == [] and base["sites"][0][1] < 0.05 * 65504.0

@@ -488,3 +488,40 @@ def test_conv_f16x2_blocks_own_their_cu(tmp_path):
     assert all(v + a == 256 for _, v, a in counts), [c for c in counts if c[1] + c[2] != 256][:4]
     src = open(os.path.join(ROOT, "r2dm_amd", "csrc", "conv_f16x2.hip")).read()
     assert re.search(r"LDS_TOTAL >= 156 \* 1024 \|\| lds_exact \? GEO::LDS_TOTAL : 156 \* 1024", src), "the launcher's LDS padding"
+
+
+def test_bench_gpus_flag_is_checked_before_anything_runs():
+    """VERDICT round 5, item 2 (no GPU needed): `--gpus N` must agree with the launcher's WORLD_SIZE, and N ranks under RCCL need N devices --
+    both fail in seconds, non-zero, with a message that names the numbers (here the device count is 0: no GPU in the CPU tier)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "R2DM_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and f"device_count() = {torch.cuda.device_count()}" in r.stderr and "--gpus 2" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", R2DM_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_schedule_on_option_and_replay_recording():
+    """setup_model(schedule_on=...) is validated and switchable (the device evaluation itself: tests/test_hip_configs.py); and the sampling
+    loop's replay state is kept only for models whose range guard can fall back (ADVICE round 5: not for 'fp32-bf16x3')."""
+    import r2dm_amd
+    from r2dm_amd.diffusion import _Replay
+
+    ddpm, _, _ = r2dm_amd.setup_model(synthetic_ckpt(), device="cpu", show_info=False)
+    assert ddpm.schedule_on == "host"
+    ddpm.set_schedule_on("device")
+    assert ddpm.schedule_on == "device" and not ddpm._on_device("cpu")  # (CPU tensors: the host path, whatever the option says)
+    with pytest.raises(ValueError):
+        ddpm.set_schedule_on("gpu")
+    with pytest.raises(ValueError):
+        r2dm_amd.setup_model(synthetic_ckpt(), device="cpu", show_info=False, schedule_on="nowhere")
+    x = torch.zeros(1)
+    for prec, rec in (("fp32", True), ("fp16", True), ("fp32-bf16x3", False)):
+        ddpm.model.set_precision(prec)
+        rp = _Replay(ddpm.model, 64)
+        rp.start(x)
+        z = rp.noise_for(0, lambda: torch.ones(1))
+        assert rp.record is rec and (rp.ck_x is x) is rec and len(rp.noise) == (1 if rec else 0) and z.item() == 1.0

@@ -130,6 +130,22 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #else
     constexpr bool EPI2 = ONEACC;
 #endif
+    // Round 6, the tile end of the one-accumulator tiles SHARED between the two wave groups (-DF2_NO_EPI3: round 5's, for A/B).  In-kernel timelines
+    // (profiles/r06_level1_timeline.txt): a tile end is 7 k cycles of the four multiplying waves' own instruction stream (8 quarters x ~0.85 k: turn, bias /
+    // residual / scale, store, statistics) -- 11-14 k with a residual, whose loads a wave can only keep four quarters of in flight -- while the four staging
+    // waves, a tile ahead, sleep at their next barrier (16 k cycles per tile end in the level-1 residual launches).  Now a multiplying wave turns its last
+    // NSQ quarters into LDS, the block meets at a barrier, and its staging partner (same wave index) finishes those -- bias from the LDS table, its own
+    // residual loads, stores, statistics -- while the multiplier finishes the first NQ - NSQ; a second barrier ends the tile.  LDS: the wave's two waiting
+    // slots (their DMA-prefetched residual is in registers by then) and, for the eight-row tile's third and fourth quarter, x buffer 1, which is dead from
+    // the tile's last barrier until the stagers' next transform -- behind the second barrier; the multipliers' 1 KiB turn patches move there too.
+#ifdef F2_NO_EPI3
+    constexpr bool EPI3 = false;
+#else
+    constexpr bool EPI3 = EPI2 && IOM == 0 && PRO != PRO_PRESPLIT;
+#endif
+    constexpr int NSQ = !EPI3 ? 0 : NR == 4 ? 4 : 2;  // quarters (the last ones: whole statistics pairs) the staging partner finishes
+    constexpr int XDUMP = NSQ > 2 ? NSQ - 2 : 0;      // ... of which so many wait in x buffer 1: [4 x 1 KiB patches][4 waves x XDUMP x 4 KiB]
+    static_assert(4096 + 4 * XDUMP * 4096 <= XBYTES, "tile-end scratch inside x buffer 1");
     // the cross products go to a second accumulator (scaled l planes) or, in the one-accumulator tiles, to the same one (l planes at their true scale)
     constexpr bool ACC2 = NPLK == 2 && !ONEACC;
     constexpr bool LSCALED = !ONEACC;
@@ -828,6 +844,85 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 if (bits > __atomic_load_n(p.gn_range + 1, __ATOMIC_RELAXED)) atomicMax(p.gn_range + 1, bits);
             }
 
+            // ---- the staging wave's share of a tile end (EPI3): quarters NQ - NSQ .. NQ - 1 of its multiplying partner (same `wave`), which that wave has
+            // turned into LDS in front of barrier E1.  Everything here is ordinary compiler-scheduled code: its own waits assume that only its own
+            // loads are in flight -- the hand-issued pixel loads and DMA pieces still in the queue are OLDER and retire first (waits get stricter,
+            // never wrong); the queue is drained before E2, so the hand-counted waits of the next iteration see what they always saw.
+            int se_item = 0;  // tiles this wave has helped to finish
+            auto tile_end_share = [&]() __attribute__((always_inline)) {
+                using gcf = const float __attribute__((address_space(1)))*;
+                using gcf4 = const f32x4 __attribute__((address_space(1)))*;
+                using gf4 = f32x4 __attribute__((address_space(1)))*;
+                constexpr int SEGW = TW / 32, Q0 = NQ - NSQ;
+                int cot, b, th, tw;
+                decode(se_item, cot, b, th, tw);
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const float sc_blk = p.scale ? *(gcf)p.scale : 1.0f, wsc = p.wscale ? *(gcf)p.wscale : 1.0f;
+                const gf4 yu = (gf4)(p.y + (long)b * p.y_bs + (long)(cot * COT) * HW);
+                const gcf4 ru = (gcf4)(p.res + (long)b * p.res_bs + (long)(cot * COT) * HW);  // (only dereferenced if p.res)
+                auto qoff = [&](int qd) __attribute__((always_inline)) {  // (f32x4 units) this lane's four pixels of channel ln >> 3 of quarter qd's first block
+                    const int n = qd % NR, sg = wave * NR + n;
+                    return ((ln >> 3) * HW + (th * TH + sg / SEGW) * W + tw * TW + (sg % SEGW) * 32 + (ln & 7) * 4) >> 2;
+                };
+                // (all NSQ quarters' residual is requested up front: VMEM operations retire in order, stores included -- a load requested behind a quarter's
+                // stores is only usable once those stores are acknowledged; first version, two buffers refilled in turn: 3 k cycles per quarter)
+                f32x4 rv[NSQ > 0 ? NSQ : 1][4] = {};
+                auto req = [&](int qd, f32x4 (&r)[4]) __attribute__((always_inline)) {
+                    if (!p.res) return;
+                    const int m = qd / NR, off = qoff(qd);
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) r[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[off];
+                };
+#pragma unroll
+                for (int k = 0; k < NSQ; ++k) req(Q0 + k, rv[k]);
+                const float* btab = reinterpret_cast<const float*>(smem + BIAS0) + (se_item & 1) * COT + (ln >> 3);
+                float amax = 0.f;
+                stamp(60);
+                __builtin_amdgcn_s_barrier();  // E1: the partner's quarters are in LDS
+                asm volatile("" ::: "memory");
+                stamp(61);
+                float ps[2][4], pq[2][4];
+#pragma unroll
+                for (int k = 0; k < NSQ; ++k) {
+                    const int qd = Q0 + k, m = qd / NR, off = qoff(qd);
+                    const float* slot = reinterpret_cast<const float*>(smem + (k < 2 ? RES0 + (wave * 2 + k) * 4096 : XBYTES + 4096 + (wave * XDUMP + (k - 2)) * 4096));
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(slot + k8 * 256 + (ln >> 3) * 32 + (ln & 7) * 4);
+                        f32x4 v = t * wsc + btab[m * 32 + k8 * 8];
+                        v = rv[k][k8] + v;  // (without a residual the buffers stay zero)
+                        v *= sc_blk;
+                        (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
+                        if (p.range) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        ps[k & 1][k8] = (v[0] + v[1]) + (v[2] + v[3]);
+                        pq[k & 1][k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                    }
+                    if ((k & 1) && p.stat) {  // a pair of quarters = one image row of one 32-channel half = one statistics slot: the multipliers' half_stats
+                        double st_s[4], st_q[4];
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {
+                            st_s[k8] = (double)ps[0][k8] + (double)ps[1][k8];
+                            st_q[k8] = (double)pq[0][k8] + (double)pq[1][k8];
+                        }
+                        const int mm = qd >> 1;
+                        if constexpr (NR == 4) epi_stat_write_bfly8(p, st_s, st_q, b, 2 * th + (wave >> 1), tw, nTw, cot * COT + (mm >> 1) * 32, 2 * (wave & 1) + (mm & 1), ln);
+                        else epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * COT + mm * 32, wave, ln);
+                    }
+                }
+                if (p.range) {
+                    const float a = wave_max_f32(amax);
+                    const int bits = __float_as_int(a);
+                    if (ln == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
+                }
+                ++se_item;
+                stamp(62);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the stores are out: the next iteration's counted waits start from an empty queue
+                stamp(63);
+                __builtin_amdgcn_s_barrier();  // E2: x buffer 1 (patches, waiting quarters) is the stagers' again
+                asm volatile("" ::: "memory");
+            };
+
             // ---- chunk q of the multipliers <-> this iteration stages chunk q+1 (three segments around the block's barriers) ----
             // Weight stage sigma is first read behind barrier B'_{sigma-1}; its ring slot is free again behind B'_{sigma} and takes
             // stage sigma+RING, due RING-1 barriers later.  One stage is requested per segment, right behind the barrier that frees
@@ -841,6 +936,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 constexpr int NEWER1 = RING == 4 ? 2 * PPW + NLp : NLp + PPW, NEWER2 = RING == 4 ? 2 * PPW + NLp : PPW,
                               NEWER3 = RING == 4 ? 2 * PPW + NLc : PPW + NLc;
                 unsigned char* nbuf = smem + ((q + 1) & 1) * XBYTES;  // x buffer of chunk q+1 (read by nobody during chunk q)
+                const bool tile_ends = x_c == 0;  // this iteration stages the NEXT tile's chunk 0: the multipliers are in their tile's last chunk
                 const bool fetch = x_c == nchunks - 2, last_of_tile = x_c == nchunks - 1;
                 const bool bias_now = EPI2 && x_c == 1;  // (nchunks >= 4: never the iteration of the table fetch or store)
                 if (fetch && !fold) table_fetch(t_item + 1);  // (one more operation in the queue: the counted waits below only get stricter)
@@ -877,6 +973,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 __builtin_amdgcn_s_barrier();        // #3 = B'_{3q+2}: publishes x(q+1)
                 stamp(18);
                 asm volatile("" ::: "memory");
+                if constexpr (EPI3) {
+                    if (tile_ends) tile_end_share();
+                }
             };
             for (int q = 0; q < Q; q += 2) {  // (Q is even: chunks per tile are)
                 stage_iter(q, set1, N1C, N0C);
@@ -1096,7 +1195,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     const float sc_blk = p.scale ? *(gcf)p.scale : 1.0f;
     const float wsc = p.wscale ? *(gcf)p.wscale : 1.0f;  // inverse of the packer's power-of-two weight scale (exact)
     float* const dump = reinterpret_cast<float*>(smem + RES0) + wave * (RESQ * 1024);
-    float* const patch = !ONEACC ? reinterpret_cast<float*>(smem + PATCH0) + wave * 256 : dump;
+    float* const patch = EPI3 ? reinterpret_cast<float*>(smem + XBYTES) + wave * 256 : !ONEACC ? reinterpret_cast<float*>(smem + PATCH0) + wave * 256 : dump;
     auto fresh_lane = [&]() __attribute__((always_inline)) {  // (per-lane constants must not be hoisted across the MFMA stream)
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -1297,7 +1396,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         constexpr int qd = decltype(QD)::value, m = qd / NR, n = qd % NR;
                         f32x4 t[4];
 #pragma unroll
-                        for (int k8 = 0; k8 < 4; ++k8) {  // (the patch is the wave's first waiting slot: its residual is in registers by now -- LDS operations of a wave are in order)
+                        for (int k8 = 0; k8 < 4; ++k8) {  // (the patch is the wave's first waiting slot -- EPI3: its KiB of x buffer 1 --: its residual is in registers by now, LDS operations of a wave are in order)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) patch[(j + 4 * hie) * 32 + l31e] = acc[m][n][4 * k8 + j];
                             t[k8] = *reinterpret_cast<const f32x4*>(patch + (ln >> 3) * 32 + (ln & 7) * 4);
@@ -1305,6 +1404,49 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         quarter(QD, t, rv, e_b, e_th, e_tw, e_cot, ln, ps, pq);
                     };
                     float ps0[4], pq0[4], ps1[4], pq1[4];
+                    if constexpr (EPI3) {
+                        // the staging partner's quarters, turned, into the two waiting slots (read out above) and x buffer 1; E1 hands them over
+                        auto dump_to = [&](auto K) __attribute__((always_inline)) {
+                            constexpr int k = decltype(K)::value;
+                            float* dst = k < 2 ? dump + k * 1024 : reinterpret_cast<float*>(smem + XBYTES + 4096 + (wave * XDUMP + (k - 2)) * 4096);
+                            turn_write(ic<NQ - NSQ + k>{}, dst, ln);
+                        };
+                        dump_to(ic<0>{});
+                        dump_to(ic<1>{});
+                        if constexpr (NSQ == 4) {
+                            dump_to(ic<2>{});
+                            dump_to(ic<3>{});
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        stamp(20);
+                        __builtin_amdgcn_s_barrier();  // E1
+                        asm volatile("" ::: "memory");
+                        do_q(ic<0>{}, rvA, ps0, pq0);
+                        stamp(21);
+                        if constexpr (NR == 4) res_request_to(rv3, ic<3>{}, e_b, e_th, e_tw, e_cot, ln);
+                        if constexpr (NQ - NSQ > 4) res_request_to(rvA, ic<4>{}, e_b, e_th, e_tw, e_cot, ln);
+                        do_q(ic<1>{}, rv1, ps1, pq1);
+                        stamp(22);
+                        if constexpr (NQ - NSQ > 4) res_request_to(rv1, ic<5>{}, e_b, e_th, e_tw, e_cot, ln);
+                        half_stats(ic<0>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                        stamp(23);
+                        if constexpr (MR == 4) bias_load(ic<1>{});
+                        do_q(ic<2>{}, rv2, ps0, pq0);
+                        stamp(24);
+                        do_q(ic<3>{}, rv3, ps1, pq1);
+                        half_stats(ic<1>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                        if constexpr (NQ - NSQ > 4) {
+                            bias_load(ic<2>{});
+                            do_q(ic<4>{}, rvA, ps0, pq0);
+                            do_q(ic<5>{}, rv1, ps1, pq1);
+                            half_stats(ic<2>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
+                        }
+                        range_flush(ln);
+                        stamp(8);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();  // E2: the staging partner is done with the waiting slots, this wave with its patch in x buffer 1
+                        asm volatile("" ::: "memory");
+                    } else {
                     stamp(20);
                     do_q(ic<0>{}, rvA, ps0, pq0);
                     stamp(21);
@@ -1332,6 +1474,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                     half_stats(ic<3>{}, ps0, pq0, ps1, pq1, e_b, e_th, e_tw, e_cot, ln);
                     range_flush(ln);
                     stamp(8);
+                    }
                     // (the accumulators restart from C = 0 in the next tile's first products: end the old values' lives)
                     if constexpr (MR == 4) {
                         asm volatile("" : "=v"(acc[0][0]), "=v"(acc[0][1]), "=v"(acc[1][0]), "=v"(acc[1][1]));

@@ -386,6 +386,7 @@ struct Ctx {
     hipError_t err = hipSuccess;
     const char* where = "";
     int f2_launches = 0;  // conv_f16x2 launches of this forward so far (odd ones walk their tiles backwards: ConvParams::reverse)
+    int last_reverse = -1;  // direction of the last conv_f16x2 launch (-1: none yet / another kernel)
     // the fp16 operand range guard, one slot per guarded producer ("site") of the forward, in walk order; `ctx`: which layer the walk is in
     int n_sites = 0;
     std::string ctx;
@@ -561,6 +562,7 @@ struct Ctx {
             if (L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded)) {
                 static const int rev_mode = getenv("R2DM_TILE_ORDER") ? atoi(getenv("R2DM_TILE_ORDER")) : 1;  // 0: always ascending (experiments)
                 p.reverse = rev_mode ? (f2_launches++ & 1) : 0;
+                last_reverse = p.reverse;
                 p.algo = ALGO_F16X2;
                 p.w = blob(L.w_f2);
                 p.wscale = blob(L.ws_f2) + 1;
@@ -592,6 +594,9 @@ struct Ctx {
             }
             if (L.p1 && h->f16_path() && pro != PRO_AFFINE_SILU && (pro != PRO_NONE || input_bounded)) {
                 p.algo = ALGO_P1F16;
+                // (a skip convolution reads the tensor its block's conv1 has just read: start where that walk ended.  R2DM_PROJ_ORDER=0: always forwards)
+                static const bool proj_rev = !getenv("R2DM_PROJ_ORDER") || atoi(getenv("R2DM_PROJ_ORDER")) != 0;
+                p.reverse = proj_rev && last_reverse == 0 ? 1 : 0;
                 p.w = blob(L.w_p1);
                 p.wscale = blob(L.ws_p1) + 1;
                 p.co_tile = 64;

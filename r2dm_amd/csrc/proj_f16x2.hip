@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) 
     const int H = p.H, W = p.W, HW = H * W;
     const int nTw = W / TW, nTh = H / TH, nCoT = p.Cout / CO_T, nchunks = p.Cin / CKP;
     int L = xcd_remap(blockIdx.x, gridDim.x);
+    if (p.reverse) L = (int)gridDim.x - 1 - L;  // (round 6: against the walk of the convolution that read the same tensor last -- Infinity Cache)
     const int cot = L % nCoT;
     L /= nCoT;
     const int tw = L % nTw;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void proj_tall_f16x2_kernel(const ConvParam
     const int H = p.H, W = p.W, HW = H * W;
     const int nTw = W / TW, nTh = H / TH, nCoB = p.Cout / COB, nchunks = p.Cin / CKP;
     int L = xcd_remap(blockIdx.x, gridDim.x);
+    if (p.reverse) L = (int)gridDim.x - 1 - L;  // (round 6: against the walk of the convolution that read the same tensor last -- Infinity Cache)
     const int cob = L % nCoB;  // (fastest: the blocks that share a pixel row follow each other)
     L /= nCoB;
     const int row = L % TH;

@@ -57,14 +57,67 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict_
 // 6 rows = 24 load instructions for 8 outputs.  (One output pair per thread was 12 loads for 2 outputs and bound by the CU's
 // address pipeline, not by HBM: 3.7 TB/s.)  Needs W % 8 == 0, H % 4 == 0; the generic kernel above takes the rest.
 // xp: the input plane, i2: pair of output rows, t: quad of output columns; v[o]: output row 2 i2 + o, columns 4t .. 4t+3
-__device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, int H, int W, int i2, int t, f32x4 (&v)[2]) {
+// Any even width and height (missing #4: the reference's Resample(down=2) takes them, ops.py:91-143; the engine's own geometries always
+// have W % 4 == 0): one thread -> one output, the same fir4 chains on the same operands as the kernels below.
+__global__ __launch_bounds__(256) void fir_down2_any_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y, long ybs, int C, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long per_plane = (long)Ho * Wo, total = per_plane * C;
+    const int b = blockIdx.y;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx / per_plane;
+        const long rem = idx % per_plane;
+        const int i = rem / Wo, j = rem % Wo;
+        const float* xp = x + b * xbs + (long)c * H * W;
+        const int c0 = 2 * j - 1 < 0 ? W - 1 : 2 * j - 1, c3 = 2 * j + 2 >= W ? 0 : 2 * j + 2;
+        float h[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int r = 2 * i + a - 1;
+            h[a] = 0.f;
+            if (r >= 0 && r < H) {
+                const float* row = xp + (long)r * W;
+                h[a] = fir4(row[c0], row[2 * j], row[2 * j + 1], row[c3]);
+            }
+        }
+        y[b * ybs + (long)c * per_plane + rem] = fir4(h[0], h[1], h[2], h[3]);
+    }
+}
+
+// SHFL (round 6): the two halo columns of a row come from the neighbouring lanes' registers (ds_bpermute: no memory instruction) instead of two 4-byte
+// loads per row -- 12 of the 24 load instructions of a patch, the ones that cost the CU's address pipeline a whole wave-wide request for 4 bytes per
+// lane.  Valid where a wave's lanes hold consecutive column quads of whole rows (Wq = W / 8 divides 64 and lane % Wq == t: launcher); the wrap of the
+// azimuth is then a lane rotation inside the row's Wq lanes.  Same operands into the same fir4 chain: bit-identical outputs.
+template <int SHFL>  // 0: halo columns by loads | 1: lane rotation inside the row's Wq lanes (Wq divides 64) | 2: lanes +-1, a wave's edge lanes load (Wq a multiple of 64)
+__device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, int H, int W, int i2, int t, f32x4 (&v)[2], int lane = 0, int Wq = 0) {
     const int cl = 8 * t - 1 < 0 ? W - 1 : 8 * t - 1;
     const int cr = 8 * t + 8 >= W ? 0 : 8 * t + 8;
+    // (SHFL) byte addresses of the lanes holding column quads t - 1 and t + 1 of this row (Wq is a power of two here)
+    const int lsrc = SHFL == 1 ? (((lane & ~(Wq - 1)) | ((t - 1) & (Wq - 1))) << 2) : (lane - 1) << 2, rsrc = SHFL == 1 ? (((lane & ~(Wq - 1)) | ((t + 1) & (Wq - 1))) << 2) : (lane + 1) << 2;
     float h[6][4];  // horizontally filtered rows 4 i2 - 1 .. 4 i2 + 4 at the four output columns
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         const int r = 4 * i2 + a - 1;
-        if (r >= 0 && r < H) {
+        const bool in = r >= 0 && r < H;
+        if constexpr (SHFL != 0) {
+            f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+            if (in) {
+                const float* row = xp + (long)r * W;
+                m0 = *reinterpret_cast<const f32x4*>(row + 8 * t);
+                m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
+            }
+            // (all lanes take part in the exchange; lanes of another row pair may be outside the image while this one is inside: their values are
+            // not read by anybody of this row)
+            float l = __int_as_float(__builtin_amdgcn_ds_bpermute(lsrc, __float_as_int(m1[3])));
+            float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(rsrc, __float_as_int(m0[0])));
+            if constexpr (SHFL == 2) {  // (lane % 64 == t % 64: the first and last lane of a wave have their neighbour in another wave -- or across the seam)
+                if (in && lane == 0) l = (xp + (long)r * W)[cl];
+                if (in && lane == 63) rr = (xp + (long)r * W)[cr];
+            }
+            h[a][0] = in ? fir4(l, m0[0], m0[1], m0[2]) : 0.f;
+            h[a][1] = in ? fir4(m0[1], m0[2], m0[3], m1[0]) : 0.f;
+            h[a][2] = in ? fir4(m0[3], m1[0], m1[1], m1[2]) : 0.f;
+            h[a][3] = in ? fir4(m1[1], m1[2], m1[3], rr) : 0.f;
+        } else if (in) {
             const float* row = xp + (long)r * W;
             const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + 8 * t), m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
             const float l = row[cl], rr = row[cr];
@@ -83,6 +136,7 @@ __device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, in
         for (int j = 0; j < 4; ++j) v[o][j] = fir4(h[2 * o][j], h[2 * o + 1][j], h[2 * o + 2][j], h[2 * o + 3][j]);
 }
 
+template <int SHFL>
 __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                              long ybs, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1, Wq = Wo >> 2, Hq = Ho >> 1;  // Wq threads per pair of output rows
@@ -94,7 +148,7 @@ __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __rest
         const long rem = idx % per_plane;
         const int i2 = rem / Wq, t = rem % Wq;
         f32x4 v[2];
-        fir_down2_patch(x + b * xbs + (long)c * H * W, H, W, i2, t, v);
+        fir_down2_patch<SHFL>(x + b * xbs + (long)c * H * W, H, W, i2, t, v, (int)threadIdx.x & 63, Wq);
 #pragma unroll
         for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v[o];
     }
@@ -108,6 +162,7 @@ __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __rest
 // column quad), lane L the patches L, L + 64, ...; fp64 from the first addition, one wave total per slot: fixed order, every slot
 // written exactly once per launch.  Groups of fewer than 64 channels use half 0 and zero half 1 (as the epilogues do); a
 // 64-channel group uses all 2 S slots.
+template <int SHFL>
 __global__ __launch_bounds__(256) void fir_down2_stats_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y, long ybs,
                                                               int cpg, int H, int W, int ipw, double* __restrict__ stat, int slots) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,7 +176,7 @@ __global__ __launch_bounds__(256) void fir_down2_stats_kernel(const float* __res
         const int c = g * cpg + cg;
         const int i2 = rem / Wq, t = rem - i2 * Wq;
         f32x4 v[2];
-        fir_down2_patch(x + b * xbs + (long)c * H * W, H, W, i2, t, v);
+        fir_down2_patch<SHFL>(x + b * xbs + (long)c * H * W, H, W, i2, t, v, lane, Wq);
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v[o];
@@ -145,6 +200,10 @@ __global__ __launch_bounds__(256) void fir_down2_stats_kernel(const float* __res
         }
     }
 }
+
+// The bilinear weights of the up-sampler as ONE spelled-out chain, shared by its two kernels (round 6; as fir4 for the down-samplers): which kernel a map
+// takes depends on its size, and a sample must come out the same bits whatever batch it is part of (tests/test_hip_configs.py).
+__device__ __forceinline__ float up1(float far, float near) { return __builtin_fmaf(0.75f, near, 0.25f * far); }  // 3/4 of the nearer sample + 1/4 of the farther one
 
 // one thread -> input columns 2t, 2t+1 of row i -> a 2x4 output patch
 // range (optional): the running maximum of |output| is merged into range[1] as float bits (positive floats order like their
@@ -171,10 +230,10 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
                 const float* row = xp + (long)r * W;
                 const float2 m = *reinterpret_cast<const float2*>(row + 2 * t);
                 const float l = row[cl], rr = row[cr];
-                h[a][0] = l * 0.25f + m.x * 0.75f;
-                h[a][1] = m.x * 0.75f + m.y * 0.25f;
-                h[a][2] = m.x * 0.25f + m.y * 0.75f;
-                h[a][3] = m.y * 0.75f + rr * 0.25f;
+                h[a][0] = up1(l, m.x);
+                h[a][1] = up1(m.y, m.x);
+                h[a][2] = up1(m.x, m.y);
+                h[a][3] = up1(rr, m.y);
             } else {
                 h[a][0] = h[a][1] = h[a][2] = h[a][3] = 0.f;
             }
@@ -182,8 +241,8 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         f32x4 e, o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            e[j] = h[0][j] * 0.25f + h[1][j] * 0.75f;
-            o[j] = h[1][j] * 0.75f + h[2][j] * 0.25f;
+            e[j] = up1(h[0][j], h[1][j]);
+            o[j] = up1(h[2][j], h[1][j]);
         }
         float* out = y + b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 4 * t;
         *reinterpret_cast<f32x4*>(out) = e;
@@ -198,6 +257,74 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         if ((threadIdx.x & 63) == 0) {
             const int bits = __float_as_int(amax);
             if (bits > __atomic_load_n(range + 1, __ATOMIC_RELAXED)) atomicMax(range + 1, bits);  // (rarely taken after the first blocks)
+        }
+    }
+}
+
+// Round 6: one thread -> input columns 4t .. 4t+3 of row i -> a 2 x 8 output patch: three 16-byte loads (rows i-1, i, i+1) and four 16-byte stores, the
+// two halo columns of a row from the neighbouring lanes' registers (ds_bpermute) -- the kernel above issues nine loads (8 + 4 + 4 bytes per row) for two
+// stores and is bound by the CU's address pipeline (4.2 TB/s).  Lanes at a wave's edge or at the azimuth seam load their halo (one or two lanes of a masked
+// instruction).  The same chains (up1) on the same operands: bit-identical to the kernel above.
+
+__global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
+                                                           long ybs, int C, int H, int W, int* __restrict__ range) {
+    float amax = 0.f;
+    const int Wt = W >> 2, Wo = W << 1;
+    const long per_plane = (long)H * Wt;
+    const long total = per_plane * C;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx / per_plane;
+        const long rem = idx % per_plane;
+        const int i = rem / Wt, t = rem % Wt;
+        const float* xp = x + b * xbs + (long)c * H * W;
+        // the lanes to the left / right hold the neighbouring quads of the same row unless this lane is first / last in its wave or in its row
+        // (a partial last wave: its active lanes are the low ones, and total is a multiple of Wt -- a right neighbour in the same row is active)
+        const bool lsh = lane > 0 && t > 0, rsh = lane < 63 && t < Wt - 1;
+        const int cl = 4 * t - 1 < 0 ? W - 1 : 4 * t - 1;
+        const int cr = 4 * t + 4 >= W ? 0 : 4 * t + 4;
+        float h[3][8];  // horizontally upsampled rows i-1, i, i+1 at output columns 8t .. 8t+7
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int r = i + a - 1;
+            const bool in = r >= 0 && r < H;  // (rows i-1 / i+1 of lanes in other rows of the wave may differ: every lane takes part in the exchange)
+            const float* row = xp + (long)(in ? r : i) * W;
+            const f32x4 m = *reinterpret_cast<const f32x4*>(row + 4 * t);
+            float l = __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 1) << 2, __float_as_int(m[3])));
+            float rr = __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) << 2, __float_as_int(m[0])));
+            if (!lsh) l = row[cl];
+            if (!rsh) rr = row[cr];
+            h[a][0] = in ? up1(l, m[0]) : 0.f;
+            h[a][1] = in ? up1(m[1], m[0]) : 0.f;
+            h[a][2] = in ? up1(m[0], m[1]) : 0.f;
+            h[a][3] = in ? up1(m[2], m[1]) : 0.f;
+            h[a][4] = in ? up1(m[1], m[2]) : 0.f;
+            h[a][5] = in ? up1(m[3], m[2]) : 0.f;
+            h[a][6] = in ? up1(m[2], m[3]) : 0.f;
+            h[a][7] = in ? up1(rr, m[3]) : 0.f;
+        }
+        float* out = y + b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 8 * t;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 e, o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[j] = up1(h[0][4 * q + j], h[1][4 * q + j]);
+                o[j] = up1(h[2][4 * q + j], h[1][4 * q + j]);
+            }
+            *reinterpret_cast<f32x4*>(out + 4 * q) = e;
+            *reinterpret_cast<f32x4*>(out + Wo + 4 * q) = o;
+            if (range) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(e[j]), fabsf(o[j])));
+            }
+        }
+    }
+    if (range) {
+        amax = wave_max_f32(amax);
+        if ((threadIdx.x & 63) == 0) {
+            const int bits = __float_as_int(amax);
+            if (bits > __atomic_load_n(range + 1, __ATOMIC_RELAXED)) atomicMax(range + 1, bits);
         }
     }
 }
@@ -222,19 +349,41 @@ int fir_down2_stat_slots(int C, int G, int H, int W) {
     return used;
 }
 
+// halo columns from the neighbouring lanes (fir_down2_patch<true>): the Wq = W / 8 column quads of a row sit in Wq consecutive lanes of one wave
+// (R2DM_FIR_SHFL=0: the loads, as until round 5 -- A/B, tests; read per call)
+static int shfl_mode(int W) {
+    const char* e = getenv("R2DM_FIR_SHFL");
+    const int Wq = W / 8;
+    if ((e && atoi(e) == 0) || W % 8 || Wq < 2) return 0;
+    return Wq <= 64 && 64 % Wq == 0 ? 1 : Wq % 64 == 0 ? 2 : 0;  // (whole rows inside a wave | whole waves inside a row)
+}
+
 hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, double* stat, int G) {
-    if ((W & 3) || (H & 1)) return hipErrorInvalidValue;
+    if ((W & 1) || (H & 1)) return hipErrorInvalidValue;
+    if (W & 3) {  // (never inside the engine: its widths are multiples of 32)
+        if (stat) return hipErrorInvalidValue;
+        fir_down2_any_kernel<<<dim3(grid_for((long)C * (H / 2) * (W / 2)), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
+        return hipGetLastError();
+    }
     if (stat) {
         const int used = fir_down2_stat_slots(C, G, H, W);
         if (!used) return hipErrorInvalidValue;
         const int cpg = C / G;
         const int ipw = (int)((long)cpg * (H / 4) * (W / 8) / used);
-        fir_down2_stats_kernel<<<dim3(used / 4, G, B), 256, 0, s>>>(x, xbs, y, ybs, cpg, H, W, ipw, stat, conv_stat_slots(H / 2, W / 2));
+        // (lane % Wq == t: a wave slot's patches start at a multiple of 64 -- fir_down2_stat_slots -- and 64 % Wq == 0)
+        const int sm = shfl_mode(W);
+        if (sm == 1) fir_down2_stats_kernel<1><<<dim3(used / 4, G, B), 256, 0, s>>>(x, xbs, y, ybs, cpg, H, W, ipw, stat, conv_stat_slots(H / 2, W / 2));
+        else if (sm == 2) fir_down2_stats_kernel<2><<<dim3(used / 4, G, B), 256, 0, s>>>(x, xbs, y, ybs, cpg, H, W, ipw, stat, conv_stat_slots(H / 2, W / 2));
+        else fir_down2_stats_kernel<0><<<dim3(used / 4, G, B), 256, 0, s>>>(x, xbs, y, ybs, cpg, H, W, ipw, stat, conv_stat_slots(H / 2, W / 2));
         return hipGetLastError();
     }
     if (W % 8 == 0 && H % 4 == 0 && getenv("R2DM_FIR_NARROW") == nullptr) {
         const long tot = (long)C * (H / 4) * (W / 8);
-        fir_down2_wide_kernel<<<dim3(grid_for(tot), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
+        // (the grid-stride loop keeps lane % Wq == t: 256 and the stride are multiples of 64, per_plane a multiple of Wq)
+        const int sm = shfl_mode(W);
+        if (sm == 1) fir_down2_wide_kernel<1><<<dim3(grid_for(tot), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
+        else if (sm == 2) fir_down2_wide_kernel<2><<<dim3(grid_for(tot), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
+        else fir_down2_wide_kernel<0><<<dim3(grid_for(tot), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
         return hipGetLastError();
     }
     const long total = (long)C * (H / 2) * (W / 4);
@@ -244,6 +393,12 @@ hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B,
 
 hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, int* range) {
     if (W & 1) return hipErrorInvalidValue;
+    const char* e = getenv("R2DM_FIR_UP_WIDE");  // (0: the two-column kernel, as until round 5; 2: the wide kernel at any size -- A/B, tests; read per call)
+    // (small maps stay on the two-column kernel: with a quarter of the threads the wide one is latency-bound -- 256 channels of 8 x 128 at batch 8: 18 -> 22 us)
+    if (W % 4 == 0 && !(e && atoi(e) == 0) && ((long)B * C * H * W >= (8L << 20) || (e && atoi(e) == 2))) {
+        fir_up2_wide_kernel<<<dim3(grid_for((long)C * H * (W / 4)), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
+        return hipGetLastError();
+    }
     const long total = (long)C * H * (W / 2);
     fir_up2_kernel<<<dim3(grid_for(total), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
     return hipGetLastError();

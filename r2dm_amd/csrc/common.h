@@ -149,6 +149,9 @@ bool conv_f16x2_fold_supported(const ConvParams& p, int groups, int slots);
 long presplit_floats(int B, int Cin, int H, int W);
 bool presplit_supported(const Src& x, int Cin, int H, int W);
 hipError_t launch_presplit(const Src& x, const float2* aff, int prologue, float* xs, int B, int Cin, int H, int W, hipStream_t s);
+// ... with the GroupNorm folded in (round 6): partial = the producers' statistics slots [B][G][stride][2], of which the first nslots per group count
+hipError_t launch_presplit_fold(const Src& x, int prologue, float* xs, int B, int Cin, int H, int W, const double* partial, int stride, int nslots, int cpg,
+                                float eps, const float* gamma, const float* beta, const float* ada, long ada_stride, int* range, hipStream_t s);
 bool proj_f16x2_supported(int Cin, int Cout, int taps, int H, int W);
 long proj_f16x2_packed_floats(int Cin, int Cout);
 hipError_t launch_pack_proj_f16x2(const float* w_oi, float* dst, int Cout, int Cin, int* range_flag, hipStream_t s, float* wscale = nullptr);

@@ -499,7 +499,7 @@ struct Ctx {
                 const NormSpec* ns = nullptr,                           // ns: `aff` comes from this GroupNorm (aff must be nullptr)
                 bool x16 = false, bool y16 = false) {                   // fp16 storage of the input / of the output (+ residual): act16(L) launches only
         // (decided in the dry walk as well, from shapes and the batch alone: the allocation sequence must be the same in both walks)
-        bool fold = false;
+        bool fold = false, pre_fold = false;
         float2* own_aff = nullptr;
         if (ns) {
             const Sink& k = *ns->stats;
@@ -513,7 +513,15 @@ struct Ctx {
                 q.reverse = 1;  // (whichever direction this launch will walk its tiles in)
                 fold = fold && conv_f16x2_fold_supported(q, G, slots);
             }
-            if (!fold) aff = own_aff = norm(k, x, H, W, ns->gamma, ns->beta, ns->ada);
+            // Round 6 EXPERIMENT, off by default (R2DM_F2_PRESPLIT_NARROW=1): the launches on 32-channel tiles (u_block4: eight output-channel tiles stage the
+            // same x tile, the stagers bound a chunk at 4.5 k cycles for 1.7 k of MFMAs) take their input through the operand pre-pass with the GroupNorm
+            // folded into THAT pass (presplit_fold_kernel): bit-identical; the convolutions go 43.8 -> 28.7 us and 78.3 -> 51.7 us, and the six 12.4 us passes
+            // (a launch + three dependent round trips over an 8 MB tensor) take it all back: step 5.894 | 5.895 ms (profiles/r06_narrow_presplit.txt).
+            if (k && narrow_presplit() && L.f2 && L.f2_cot == 32 && L.f2_rows == 4 && h->conv_pieces == 2 && G == 8 && k.C == L.cin && presplit_supported(x, L.cin, H, W)) {
+                fold = false;
+                pre_fold = true;
+            }
+            if (!fold && !pre_fold) aff = own_aff = norm(k, x, H, W, ns->gamma, ns->beta, ns->ada);
         }
         Tensor y;
         y.C = L.cout;
@@ -535,6 +543,7 @@ struct Ctx {
         float* xs = nullptr;
         if (f2_launch && !fold && L.f2_cot == 64 && L.f2_rows == 4 && presplit_min_cout > 0 && L.cout >= presplit_min_cout && presplit_supported(x, L.cin, H, W))
             xs = (float*)ar->alloc((size_t)presplit_floats(B, L.cin, H, W) * sizeof(float));
+        if (f2_launch && pre_fold && !xs) xs = (float*)ar->alloc((size_t)presplit_floats(B, L.cin, H, W) * sizeof(float));
         if (!dry()) {
             ConvParams p;
             p.x = x;
@@ -587,7 +596,12 @@ struct Ctx {
             }
             // deep layers (many 64-channel output tiles): the input transform once, by the pre-pass (presplit.hip)
             if (xs) {
-                note(launch_presplit(x, aff, pro, xs, B, L.cin, H, W, st), "presplit");
+                if (pre_fold) {
+                    const Sink& k = *ns->stats;
+                    note(launch_presplit_fold(x, pro, xs, B, L.cin, H, W, k.p, k.slots, k.cpg < 64 ? k.slots / 2 : k.slots, k.cpg, h->cfg.gn_eps, ns->gamma, ns->beta, ns->ada,
+                                              (long)h->ada_rows, range_site("GroupNorm output bound |a| M + |d| (folded into the operand pre-pass)"), st), "presplit_fold");
+                } else
+                    note(launch_presplit(x, aff, pro, xs, B, L.cin, H, W, st), "presplit");
                 p.x = Src{xs, nullptr, L.cin, 0, presplit_floats(1, L.cin, H, W), 0};
                 p.prologue = PRO_PRESPLIT;
                 p.aff = nullptr;
@@ -653,6 +667,10 @@ struct Ctx {
     bool act16(const ConvLayer& L) const {
         static const bool on = !getenv("R2DM_FP16_STORAGE") || atoi(getenv("R2DM_FP16_STORAGE")) != 0;
         return on && h->conv_pieces == 1 && L.f2 && !(L.f2_cot == 32 && narrow_split());
+    }
+    static bool narrow_presplit() {
+        const char* e = getenv("R2DM_F2_PRESPLIT_NARROW");  // (read per call, like R2DM_GN_FOLD: the bit-identity test builds one model per setting)
+        return e && atoi(e) != 0;
     }
     // (experiment switch, round 5) layers packed for the 32-channel tile run the two-plane kernel in every precision mode
     static bool narrow_split() {

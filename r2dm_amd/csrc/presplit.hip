@@ -14,6 +14,8 @@
 // element (the tensor was just written by its producer: L2 / Infinity Cache hits).
 #include "common.h"
 #include "f16x2.h"
+#include "gn_math.h"
+#include "wave_ops.h"
 
 namespace r2dm {
 
@@ -21,28 +23,20 @@ namespace {
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 // One thread = one staging unit of conv_f16x2 (8 channels x 4 consecutive pixels of one row), same expressions in the same order
-// as the stagers' `xf` (conv_f16x2.hip): affine, SiLU on v_exp / v_rcp, split_f16x2.
-template <int PRO>
-__global__ __launch_bounds__(256) void presplit_kernel(const Src x, const float2* __restrict__ aff, unsigned short* __restrict__ xs,
-                                                       int Cin, int H, int W) {
-    f16_saturate_mode();
+// as the stagers' `xf` (conv_f16x2.hip): affine, SiLU on v_exp / v_rcp, split_f16x2.  ad4[j] = (a, d) of channels 2 j, 2 j + 1.
+__device__ __forceinline__ void presplit_load(const Src& x, f32x4 (&raw)[8], int H, int W, int unit, int c8, int b) {
     const int nq = W >> 2;                         // quads per row
-    const int unit = blockIdx.x * 256 + threadIdx.x;  // (row, quad) of the image, row-major
-    const int c8 = blockIdx.y, b = blockIdx.z;     // 8-channel group (global), sample
-    if (unit >= H * nq) return;
     const int row = unit / nq, quad = unit - row * nq;
     const long HW = (long)H * W;
-    const int ci0 = c8 * 8;
-    const float* src = x.plane(b, ci0, HW) + (long)row * W + quad * 4;  // (a group of 8 never straddles the concat seam: launcher)
-    f32x4 raw[8];
+    const float* src = x.plane(b, c8 * 8, HW) + (long)row * W + quad * 4;  // (a group of 8 never straddles the concat seam: launcher)
 #pragma unroll
     for (int i = 0; i < 8; ++i) raw[i] = *reinterpret_cast<const f32x4*>(src + i * HW);
-    f32x4 ad4[4];
-    if (PRO != PRO_NONE) {
-        const f32x4* ap = reinterpret_cast<const f32x4*>(aff + (long)b * Cin + ci0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ad4[j] = ap[j];
-    }
+}
+
+template <int PRO>
+__device__ __forceinline__ void presplit_unit(const f32x4 (&raw)[8], const f32x4 (&ad4)[4], unsigned short* __restrict__ xs, int Cin, int H, int W, int unit, int c8, int b) {
+    const int nq = W >> 2;                         // quads per row
+    const int row = unit / nq, quad = unit - row * nq;
     unsigned ph[4][4], pl[4][4];  // [pixel][channel pair]
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -93,6 +87,108 @@ __global__ __launch_bounds__(256) void presplit_kernel(const Src x, const float2
         }
     }
 }
+
+template <int PRO>
+__global__ __launch_bounds__(256) void presplit_kernel(const Src x, const float2* __restrict__ aff, unsigned short* __restrict__ xs,
+                                                       int Cin, int H, int W) {
+    f16_saturate_mode();
+    const int unit = blockIdx.x * 256 + threadIdx.x;  // (row, quad) of the image, row-major
+    const int c8 = blockIdx.y, b = blockIdx.z;     // 8-channel group (global), sample
+    if (unit >= H * (W >> 2)) return;
+    f32x4 raw[8];
+    presplit_load(x, raw, H, W, unit, c8, b);
+    f32x4 ad4[4] = {};
+    if (PRO != PRO_NONE) {
+        const f32x4* ap = reinterpret_cast<const f32x4*>(aff + (long)b * Cin + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ad4[j] = ap[j];
+    }
+    presplit_unit<PRO>(raw, ad4, xs, Cin, H, W, unit, c8, b);
+}
+
+// Round 6: the same pass with the GroupNorm in front of the convolution FOLDED IN (as conv_f16x2.hip's staging waves fold it): every block
+// reduces the statistics slots of its sample's group itself -- gn_finalize_kernel's reduction, slot assignment, order and arithmetic (norm.hip,
+// gn_math.h: the same bits) -- and derives (a, d) of its eight channels; no gn_finalize launch, no (a, d) tensor.  For the launches whose
+// output-channel tiles are many and small (u_block4 on 32-channel tiles: eight blocks stage the same x tile, the stagers bound a chunk at 4.5 k
+// cycles for 1.7 k of MFMAs).  range (optional): the group's bound (gn_bound) as gn_finalize records it.
+template <int PRO>
+__global__ __launch_bounds__(256) void presplit_fold_kernel(const Src x, unsigned short* __restrict__ xs, int Cin, int H, int W,
+                                                            const double* __restrict__ partial, int stride, int nslots, int cpg, float eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ ada, long ada_stride, int* __restrict__ range) {
+    f16_saturate_mode();
+    const int c8 = blockIdx.y, b = blockIdx.z, G = Cin / cpg, g = (c8 * 8) / cpg;
+    const int unit = blockIdx.x * 256 + threadIdx.x;
+    const bool live = unit < H * (W >> 2);
+    // everything that does not depend on the statistics is requested first: this thread's pixels and the norm's parameters of the block's eight channels
+    f32x4 raw[8];
+    presplit_load(x, raw, H, W, live ? unit : 0, c8, b);
+    float w8[8], sh8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        if (ada) {
+            w8[i] = ada[b * ada_stride + c];
+            sh8[i] = ada[b * ada_stride + Cin + c];
+        } else {
+            w8[i] = gamma ? gamma[c] : 1.0f;
+            sh8[i] = beta ? beta[c] : 0.0f;
+        }
+    }
+    using d2 = __attribute__((ext_vector_type(2))) double;
+    const d2* p2 = reinterpret_cast<const d2*>(partial + ((long)b * G + g) * stride * 2);
+    double sum = 0.0, sq = 0.0, emax = 0.0;
+    for (int s0 = threadIdx.x; s0 < nslots; s0 += 256 * 8) {  // (gn_finalize_kernel's loop: thread t adds slots t, t + 256, ... in ascending order)
+        d2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sl = s0 + 256 * i;
+            v[i] = sl < nslots ? p2[sl] : d2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sum += v[i][0];
+            sq += v[i][1];
+            emax = v[i][1] > emax ? v[i][1] : emax;
+        }
+    }
+    const bool bound_here = range && blockIdx.x == 0;  // (one block per (sample, 8 channels) records the bound: block-uniform)
+    float gmax = bound_here ? wave_max_f32((float)sqrt(emax) * 1.000001f) : 0.f;
+    __shared__ double red[2][4];
+    __shared__ float redm[4];
+    sum = wave_sum_f64_hi_first(sum);
+    sq = wave_sum_f64_hi_first(sq);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sum;
+        red[1][threadIdx.x >> 6] = sq;
+        redm[threadIdx.x >> 6] = gmax;
+    }
+    __syncthreads();
+    sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double n = (double)cpg * (double)H * (double)W;
+    const GnMoments mo = gn_moments(sum, sq, n, eps);
+    f32x4 ad4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float w0 = ada ? 1.0f + w8[2 * j] : w8[2 * j], w1 = ada ? 1.0f + w8[2 * j + 1] : w8[2 * j + 1];
+        const float2 e0 = gn_affine(mo, w0, sh8[2 * j]), e1 = gn_affine(mo, w1, sh8[2 * j + 1]);
+        ad4[j] = f32x4{e0.x, e0.y, e1.x, e1.y};
+    }
+    if (bound_here && threadIdx.x == 0) {
+        gmax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        float bound = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float w = ada ? 1.0f + w8[i] : w8[i];
+            const float bd = gn_bound(mo, gn_affine(mo, w, sh8[i]), w, sh8[i], gmax, n);
+            bound = __float_as_int(bd) > __float_as_int(bound) ? bd : bound;  // (as ints: positive floats order like their bit patterns, a NaN above all)
+        }
+        atomicMax(range + 1, __float_as_int(bound));
+    }
+    if (!live) return;
+    presplit_unit<PRO>(raw, ad4, xs, Cin, H, W, unit, c8, b);
+}
 }  // namespace
 
 // floats (4-byte units) of the pre-split tensor of a (B, Cin, H, W) activation
@@ -110,6 +206,19 @@ hipError_t launch_presplit(const Src& x, const float2* aff, int prologue, float*
         case PRO_NONE: presplit_kernel<PRO_NONE><<<grid, 256, 0, s>>>(x, aff, dst, Cin, H, W); break;
         case PRO_AFFINE: presplit_kernel<PRO_AFFINE><<<grid, 256, 0, s>>>(x, aff, dst, Cin, H, W); break;
         case PRO_AFFINE_SILU: presplit_kernel<PRO_AFFINE_SILU><<<grid, 256, 0, s>>>(x, aff, dst, Cin, H, W); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_presplit_fold(const Src& x, int prologue, float* xs, int B, int Cin, int H, int W, const double* partial, int stride, int nslots, int cpg,
+                                float eps, const float* gamma, const float* beta, const float* ada, long ada_stride, int* range, hipStream_t s) {
+    if (!presplit_supported(x, Cin, H, W) || !partial || cpg < 8 || cpg % 8 || Cin % cpg || nslots < 1 || nslots > stride || (x.p1 && x.c0 % cpg)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((H * (W / 4) + 255) / 256), (unsigned)(Cin / 8), (unsigned)B);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(xs);
+    switch (prologue) {
+        case PRO_AFFINE: presplit_fold_kernel<PRO_AFFINE><<<grid, 256, 0, s>>>(x, dst, Cin, H, W, partial, stride, nslots, cpg, eps, gamma, beta, ada, ada_stride, range); break;
+        case PRO_AFFINE_SILU: presplit_fold_kernel<PRO_AFFINE_SILU><<<grid, 256, 0, s>>>(x, dst, Cin, H, W, partial, stride, nslots, cpg, eps, gamma, beta, ada, ada_stride, range); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -427,6 +427,35 @@ def test_group_norm_folded_into_its_consumer_is_bit_identical(res, batch):
     assert torch.equal(outs["1"][0], outs["0"][0])
 
 
+@pytest.mark.parametrize("res,batch", [((64, 1024), 8), ((64, 1024), 2), ((128, 2048), 2)])
+def test_operand_prepass_with_folded_group_norm_is_bit_identical(res, batch):
+    """Round 6: the launches on 32-channel output tiles (u_block4 at batch 8) take their input through the operand pre-pass with the GroupNorm folded
+    into it (presplit.hip presplit_fold_kernel: gn_finalize_kernel's reduction and gn_math.h's arithmetic, the stagers' own transform) instead of
+    transforming it in the staging waves of eight blocks.  Same (a, d), same products: against R2DM_F2_PRESPLIT_NARROW=0 bit for bit, at a batch
+    where the 32-channel tiles are dispatched and at ones where they are not (then nothing changes at all)."""
+    import r2dm_amd
+
+    ck = synthetic_ckpt(resolution=res)
+    x, c = rnd(9, batch, 2, *res).to(DEV), torch.linspace(-5.0, 7.0, batch).to(DEV)
+    outs = {}
+    saved = os.environ.get("R2DM_F2_PRESPLIT_NARROW")
+    for mode in ("1", "0"):
+        os.environ["R2DM_F2_PRESPLIT_NARROW"] = mode
+        try:
+            m, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=batch)
+            outs[mode] = (m.model(x, c).clone(), m.model(x, c).clone())
+            sites = [n for n, _ in m.model.range_report()]
+            if mode == "1" and res == (64, 1024) and batch == 8:
+                assert any("operand pre-pass" in n for n in sites), sites[:5]  # (the path under test really ran)
+            del m
+        finally:
+            os.environ.pop("R2DM_F2_PRESPLIT_NARROW", None)
+            if saved is not None:
+                os.environ["R2DM_F2_PRESPLIT_NARROW"] = saved
+    assert torch.equal(outs["1"][0], outs["1"][1]) and torch.equal(outs["0"][0], outs["0"][1])
+    assert torch.equal(outs["1"][0], outs["0"][0])
+
+
 @pytest.mark.parametrize("res,batch", [((64, 1024), 8), ((32, 256), 2), ((128, 2048), 2)])
 def test_fir_down_statistics_match_the_streaming_pass(res, batch):
     """Round 5: the FIR down-sampler leaves the GroupNorm statistics of its output in the convolution epilogues' slot grid (resample.hip

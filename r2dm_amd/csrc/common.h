@@ -11,6 +11,42 @@ constexpr float kInvSqrt2 = 0.70710678118654752440f;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// fp16 STORAGE of activations (the one-plane mode, round 5 / 6): four consecutive pixels of one channel are 8 bytes.  Pointers stay typed float*; an
+// element index e of an fp16 tensor is the byte offset 2 e.  Conversions are RNE (v_cvt_pk_f16_f32) / exact (fp16 -> fp32).
+using f16x2v = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ f32x4 f16x4_to_f32(unsigned long long r) {
+    return f32x4{(float)__builtin_bit_cast(_Float16, (unsigned short)r), (float)__builtin_bit_cast(_Float16, (unsigned short)(r >> 16)),
+                 (float)__builtin_bit_cast(_Float16, (unsigned short)(r >> 32)), (float)__builtin_bit_cast(_Float16, (unsigned short)(r >> 48))};
+}
+__device__ __forceinline__ unsigned long long f32_to_f16x4(const f32x4& v) {
+    using f32x2v = __attribute__((ext_vector_type(2))) float;
+    return (unsigned long long)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v[0], v[1]}, f16x2v)) |
+           ((unsigned long long)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v[2], v[3]}, f16x2v)) << 32);
+}
+// four consecutive elements starting at element index `e` (a multiple of 4) of a tensor stored as fp32 (X16 = false) or fp16
+template <bool X16>
+__device__ __forceinline__ f32x4 load4(const float* base, long e) {
+    if constexpr (X16) return f16x4_to_f32(*reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(base) + e));
+    else return *reinterpret_cast<const f32x4*>(base + e);
+}
+template <bool X16>
+__device__ __forceinline__ float load1(const float* base, long e) {
+    if constexpr (X16) return (float)__builtin_bit_cast(_Float16, reinterpret_cast<const unsigned short*>(base)[e]);
+    else return base[e];
+}
+// stores v (RNE for fp16) and returns the values AS STORED (what a consumer will read: statistics and range maxima are taken of those)
+template <bool Y16>
+__device__ __forceinline__ f32x4 store4(float* base, long e, const f32x4& v) {
+    if constexpr (Y16) {
+        const unsigned long long pk = f32_to_f16x4(v);
+        *reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(base) + e) = pk;
+        return f16x4_to_f32(pk);
+    } else {
+        *reinterpret_cast<f32x4*>(base + e) = v;
+        return v;
+    }
+}
+
 // A (B, C0+C1, H, W) activation that may live in two allocations (channel concat without a copy,
 // reference efficient_unet.py:11-12,290-292).  Planes are H*W contiguous floats; `bs` is the batch
 // stride in floats (0 = broadcast over the batch, used for the constant coordinate encoding).
@@ -185,10 +221,10 @@ hipError_t launch_gn_apply(const float* x, const float2* aff, float* y, int B, i
 // stat != nullptr: the GroupNorm statistics of the OUTPUT (G groups) go to the convolution epilogues' slot grid
 // ([B][G][conv_stat_slots(H / 2, W / 2)][2] doubles); only where fir_down2_stat_slots(C, G, H, W) != 0
 hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
-                            hipStream_t s, double* stat = nullptr, int G = 0);
+                            hipStream_t s, double* stat = nullptr, int G = 0, int x16 = 0, int y16 = 0);  // x16 / y16: fp16 storage of the input / output (round 6)
 int fir_down2_stat_slots(int C, int G, int H, int W);
 hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W,
-                          hipStream_t s, int* range = nullptr);  // range[1]: running max |output| as float bits (may be nullptr)
+                          hipStream_t s, int* range = nullptr, int x16 = 0, int y16 = 0);  // range[1]: running max |output| as float bits (may be nullptr)
 
 // qkv: (B, 3C, N) channel-major [q | k | v]; out (B, C, N)
 // planes: 0 = fp32-input MFMA, 2 = fp16 matrix pipe with split operands, 1 = fp16 matrix pipe, one product (attention.hip)

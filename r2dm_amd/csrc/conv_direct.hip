@@ -34,7 +34,7 @@ constexpr int TH = 4, TW = 64, XR = TH + 2, XS = TW + 2, CK = 8, MAXCO = 4;
 #ifndef DC_ROWS
 #define DC_ROWS 2
 #endif
-template <int CO>
+template <int CO, bool X16 = false>  // X16 (round 6): the input tensor is stored as fp16 (the one-plane mode's activation storage)
 __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams p) {
     using gcf = const float __attribute__((address_space(1)))*;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[o][i][j] = 0.f;
-    const float* xb0 = p.x.p0 + b * p.x.bs0;
-    const float* xb1 = p.x.p1 ? p.x.p1 + b * p.x.bs1 : p.x.p0;
+    // (fp16 input: the batch offset in halves)
+    const float* xb0 = X16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.x.p0) + b * p.x.bs0) : p.x.p0 + b * p.x.bs0;
+    const float* xb1 = !p.x.p1 ? xb0 : X16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.x.p1) + b * p.x.bs1) : p.x.p1 + b * p.x.bs1;
     const int c0 = p.x.p1 ? p.x.c0 : p.Cin;
     const gcf wg = (gcf)p.w;
 #ifndef DC_UNROLL
@@ -75,12 +76,23 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
 #endif
 #pragma unroll DC_UNROLL
     for (int ci = 0; ci < p.Cin; ++ci) {
-        const gcf pl = (gcf)(ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW);
         float x[R + 2][6];
 #pragma unroll
         for (int k = 0; k < R + 2; ++k) {
-            const f32x4 v = *(gcf4)(pl + rbase[k] + gc);
-            const float l = pl[rbase[k] + cl], r = pl[rbase[k] + cr];
+            f32x4 v;
+            float l, r;
+            if constexpr (X16) {  // (batch strides and plane offsets are in ELEMENTS: load4 / load1 address halves)
+                const float* plx = ci < c0 ? xb0 : xb1;
+                const long e0 = (long)(ci < c0 ? ci : ci - c0) * HW + rbase[k];
+                v = load4<true>(plx, e0 + gc);
+                l = load1<true>(plx, e0 + cl);
+                r = load1<true>(plx, e0 + cr);
+            } else {
+                const gcf pl = (gcf)(ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW);
+                v = *(gcf4)(pl + rbase[k] + gc);
+                l = pl[rbase[k] + cl];
+                r = pl[rbase[k] + cr];
+            }
             x[k][0] = rok[k] ? l : 0.f;
             x[k][5] = rok[k] ? r : 0.f;
 #pragma unroll
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
 // map, batch-broadcast, from L2), bias, scale and one 16-byte store.  Fused GroupNorm statistics: four pixels in fp32, fp64
 // beyond, one wave_sum per group, written into the slot grid the MFMA epilogues use (conv_stat_slots: 8 slots per 4 x 64
 // tile and group -- this wave fills the first one of its row's four tiles and zeroes the other seven).
-template <int CI>
+template <int CI, bool Y16 = false>  // Y16 (round 6): the output is stored as fp16 (RNE); statistics of the values as stored
 __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
     using gcf = const float __attribute__((address_space(1)))*;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
@@ -198,7 +210,8 @@ __global__ __launch_bounds__(256) void conv_few_in_kernel(const ConvParams p) {
             if (p.res) v = rv[o] + v;
             v *= sc;  // (1.0f without p.scale: exact)
             if (active) {
-                *(gf4)(p.y + b * p.y_bs + (long)(co0 + o) * HW + pix) = v;
+                if constexpr (Y16) v = store4<true>(p.y, b * p.y_bs + (long)(co0 + o) * HW + pix, v);
+                else *(gf4)(p.y + b * p.y_bs + (long)(co0 + o) * HW + pix) = v;
                 if (p.stat) {
                     gs += (double)((v[0] + v[1]) + (v[2] + v[3]));
                     gq += (double)fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -242,6 +255,16 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s) {
         unsigned split = 1;
         while ((int)split * 2 <= max_split && p.Cout % ((int)split * 2 * unit) == 0 && nbx * split < 2048) split *= 2;
         const dim3 nb(nbx, split);
+        if (p.x16) return hipErrorInvalidValue;  // (the network input is fp32)
+        if (p.y16) {
+            switch (p.Cin) {
+                case 1: conv_few_in_kernel<1, true><<<nb, 256, 0, s>>>(p); break;
+                case 2: conv_few_in_kernel<2, true><<<nb, 256, 0, s>>>(p); break;
+                case 3: conv_few_in_kernel<3, true><<<nb, 256, 0, s>>>(p); break;
+                default: conv_few_in_kernel<4, true><<<nb, 256, 0, s>>>(p); break;
+            }
+            return hipGetLastError();
+        }
         switch (p.Cin) {
             case 1: conv_few_in_kernel<1><<<nb, 256, 0, s>>>(p); break;
             case 2: conv_few_in_kernel<2><<<nb, 256, 0, s>>>(p); break;
@@ -253,6 +276,16 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s) {
     if (!conv_direct_supported(p.Cout, p.taps) || p.prologue != PRO_NONE || p.res || p.scale || p.stat) return hipErrorInvalidValue;
     if (p.W % 4 == 0) {  // (rows of 16-byte vectors: every U-Net geometry)
         const unsigned nb = (unsigned)(((p.W + 255) / 256) * ((p.H + 4 * DC_ROWS - 1) / (4 * DC_ROWS)) * p.B);
+        if (p.y16) return hipErrorInvalidValue;  // (the network output is fp32)
+        if (p.x16) {
+            switch (p.Cout) {
+                case 1: conv_direct_rows_kernel<1, true><<<nb, 256, 0, s>>>(p); break;
+                case 2: conv_direct_rows_kernel<2, true><<<nb, 256, 0, s>>>(p); break;
+                case 3: conv_direct_rows_kernel<3, true><<<nb, 256, 0, s>>>(p); break;
+                default: conv_direct_rows_kernel<4, true><<<nb, 256, 0, s>>>(p); break;
+            }
+            return hipGetLastError();
+        }
         switch (p.Cout) {
             case 1: conv_direct_rows_kernel<1><<<nb, 256, 0, s>>>(p); break;
             case 2: conv_direct_rows_kernel<2><<<nb, 256, 0, s>>>(p); break;

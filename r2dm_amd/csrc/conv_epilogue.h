@@ -130,7 +130,8 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
 // Explicit global address space everywhere: a pointer that reaches a load through a phi is otherwise accessed with FLAT
 // instructions, which count on lgkmcnt as well and turn every LDS wait into a wait for HBM.
 // conv_f16x2.hip has its own arrangement of the same steps (one quarter at the tile's end, three deferred into the next tile).
-template <int TH, int TW, int MR, int NR, bool ACC2>
+// Y16 (round 6): the output -- and the residual -- are stored as fp16 (the one-plane mode's activation storage); statistics and range of the values as stored.
+template <int TH, int TW, int MR, int NR, bool ACC2, bool Y16 = false>
 __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (&acc)[MR][NR],
                                                    f32x16 (&acc2)[ACC2 ? MR : 1][ACC2 ? NR : 1], int b, int th, int tw,
                                                    int nTw, int co_u, int wave_px, int lane, float* patch,
@@ -163,7 +164,10 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
     auto load_q = [&](int m, int n, f32x4 (&r)[4]) __attribute__((always_inline)) {
         if (p.res) {
 #pragma unroll
-            for (int k8 = 0; k8 < 4; ++k8) r[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]];
+            for (int k8 = 0; k8 < 4; ++k8) {
+                if constexpr (Y16) r[k8] = load4<true>(p.res, b * p.res_bs + (long)co_u * HW + 4 * ((long)(m * 32 + k8 * 8) * (HW >> 2) + loff[n]));
+                else r[k8] = (ru + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]];
+            }
         }
     };
     float amax = 0.f;  // running max |output| (p.range)
@@ -193,7 +197,8 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams& p, f32x16 (
                 f32x4 v = t[k8] * out_scale + bias[m][k8];
                 if (p.res) v = rv[q & 1][k8] + v;
                 if (p.scale) v *= sc;
-                (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]] = v;
+                if constexpr (Y16) v = store4<true>(p.y, b * p.y_bs + (long)co_u * HW + 4 * ((long)(m * 32 + k8 * 8) * (HW >> 2) + loff[n]), v);
+                else (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[loff[n]] = v;
                 if (p.range) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (p.stat) {
                     const float s4 = (v[0] + v[1]) + (v[2] + v[3]);

@@ -415,14 +415,20 @@ struct Ctx {
     }
     const float* blob(size_t off) const { return h->blob + off; }
 
-    Tensor make(int C, int H, int W) {
+    Tensor make(int C, int H, int W, bool f16 = false) {
         Tensor t;
         t.C = C;
         t.H = H;
         t.W = W;
+        t.f16 = f16;
         t.p = (float*)ar->alloc(t.bytes(B));
         return t;
     }
+    // fp16 storage of EVERY activation of the two full-resolution levels (round 6; the one-plane mode = the reference's fp16 autocast, which stores its
+    // activations as fp16: /root/reference/sample_and_save.py:45,70): those levels hold 92 % of a forward's activation bytes and their launches are the ones next
+    // to the HBM roof; levels 3 and 4 (attention, 1 x 1 projections with residuals and statistics) stay fp32.  all16: decided once per forward (run_forward).
+    bool all16 = false;
+    bool lvl16(int Hres) const { return all16 && 2 * Hres >= h->cfg.height; }
     void drop(const Tensor& t) { ar->release(t.p); }
 
     // Fused statistics: a convolution whose output feeds a GroupNorm leaves per-(sample, group) partial sums in a
@@ -566,6 +572,8 @@ struct Ctx {
             p.algo = L.algo;
             p.pieces = 3;
             p.prologue = pro;
+            p.x16 = x16;  // (conv_f16x2 launches, the direct in / out convolutions and the fp16-operand skip convolutions take them; checked below)
+            p.y16 = y16;
             // the fp16 split where the input's range is guarded: GroupNorm-normalised (gn_finalize's bound) or tracked by its
             // producer (fir_up2's running maximum)
             if (L.f2 && h->f16_path() && (pro != PRO_NONE || input_bounded)) {
@@ -625,6 +633,8 @@ struct Ctx {
                 p.stat_cpg = sink->cpg;
                 p.stat_slots = sink->slots;
             }
+            if ((x16 || y16) && p.algo != ALGO_F16X2 && p.algo != ALGO_DIRECT && p.algo != ALGO_P1F16) note(hipErrorInvalidValue, "fp16 storage on a kernel without it");
+            if (x16 && !fold && !pre_fold && own_aff && !(ns && *ns->stats)) note(hipErrorInvalidValue, "fp16 storage behind a streaming GroupNorm");
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof_on) {
                 if (h->prof_used + 2 > h->prof_ev.size()) {
@@ -679,20 +689,21 @@ struct Ctx {
     }
 
     Tensor residual_block(const ResLayer& r, const Src& x, int H, int W, const Sink& in_stats, const Sink* out, int out_goff,
-                          bool track_out = false, bool skip_bounded = false) {
+                          bool track_out = false, bool skip_bounded = false, bool x16 = false) {  // x16: the block's input (both sources) is stored as fp16
         const std::string blk = ctx;
         ctx = blk + ".conv1";
         const NormSpec n1{&in_stats, blob(r.g1), blob(r.b1), nullptr};
         Sink s1 = make_sink(r.cout, H, W);
         const bool t1_16 = act16(r.conv1) && act16(r.conv2) && s1.p != nullptr;  // (the streaming statistics pass reads fp32)
-        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, nullptr, nullptr, 0, false, nullptr, &s1, 0, false, false, false, &n1, false, t1_16);
+        const bool out16 = x16 && lvl16(H) && act16(r.conv2);  // the block's output (and the residual it adds: its input or the skip convolution's output)
+        Tensor t1 = conv(r.conv1, x, H, W, PRO_AFFINE_SILU, nullptr, nullptr, 0, false, nullptr, &s1, 0, false, false, false, &n1, x16, t1_16);
         const NormSpec n2{&s1, nullptr, nullptr, proj + r.ada_row};
         Tensor skip;
         const Tensor* res;
         Tensor ident;
         if (r.has_skip) {
             ctx = blk + ".skip";
-            skip = conv(r.skip, x, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, skip_bounded);
+            skip = conv(r.skip, x, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, skip_bounded, false, nullptr, x16, out16);
             res = &skip;
         } else {
             ident.p = const_cast<float*>(x.p0);  // identity skip: block input is single-source here
@@ -702,7 +713,7 @@ struct Ctx {
             res = &ident;
         }
         ctx = blk + ".conv2";
-        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, nullptr, res, r.scale, true, nullptr, out, out_goff, false, false, track_out, &n2, t1_16, false);
+        Tensor o = conv(r.conv2, src1(t1), H, W, PRO_AFFINE_SILU, nullptr, res, r.scale, true, nullptr, out, out_goff, false, false, track_out, &n2, t1_16, out16);
         ctx = blk;
         drop_sink(s1);
         drop(t1);
@@ -735,20 +746,22 @@ struct Ctx {
     // efficient_unet.py:178-185.  Never frees `in`; returns a fresh tensor.  `in_stats`: fused statistics of `in` for
     // the first residual block (stages without downsampling); `out`/`out_goff`: sink of the GroupNorm that will consume
     // this stage's output (written by whichever convolution produces it last).
-    Tensor stage(const Stage& s, const Src& in, int H, int W, const Sink& in_stats, const Sink* out, int out_goff, bool in_tracked = false) {
+    Tensor stage(const Stage& s, const Src& in, int H, int W, const Sink& in_stats, const Sink* out, int out_goff, bool in_tracked = false, bool in16 = false) {
         Tensor cur;
         bool have = false;
+        bool c16 = in16;  // the current tensor (stage input or `cur`) is stored as fp16
         Sink carry = in_stats;  // statistics of the current tensor, owned elsewhere for the stage input
         bool carry_owned = false;
         if (s.down) {
             ctx = s.name + ".downsample";
-            Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, in_tracked);
-            cur = make(s.cout, H / 2, W / 2);
+            Tensor t = conv(s.dconv, in, H, W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, nullptr, 0, false, in_tracked, false, nullptr, in16, in16 && lvl16(H));
+            cur = make(s.cout, H / 2, W / 2, t.f16 && lvl16(H / 2));
             // the FIR pass leaves the statistics of its output for the first residual block's norm (resample.hip; where its geometry
             // does not fit the slot grid: no fused statistics, the streaming pass)
             Sink fs;
             if (fir_down2_stat_slots(s.cout, h->cfg.gn_num_groups, H, W)) fs = make_sink(s.cout, H / 2, W / 2);
-            if (!dry()) note(launch_fir_down2(t.p, t.bs(), cur.p, cur.bs(), B, s.cout, H, W, st, fs.p, h->cfg.gn_num_groups), "fir_down2");
+            if (!dry()) note(launch_fir_down2(t.p, t.bs(), cur.p, cur.bs(), B, s.cout, H, W, st, fs.p, h->cfg.gn_num_groups, t.f16, cur.f16), "fir_down2");
+            c16 = cur.f16;
             drop(t);
             H /= 2;
             W /= 2;
@@ -771,7 +784,8 @@ struct Ctx {
             }
             const bool tf = h->f16_path() && last && ((s.out_tracked) || (s.track_final && !s.attn && !s.up));
             ctx = s.name + ".residual_blocks." + std::to_string(i);
-            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, tf, i == 0 && s.skip_in_bounded && h->f16_path());
+            Tensor nxt = residual_block(s.res[i], have ? src1(cur) : in, H, W, carry, dst, goff, tf, i == 0 && s.skip_in_bounded && h->f16_path(), c16);
+            c16 = nxt.f16;
             if (carry_owned) drop_sink(carry);
             if (have) drop(cur);
             cur = nxt;
@@ -781,6 +795,7 @@ struct Ctx {
         }
         if (s.attn) {
             ctx = s.name + ".self_attn_block";
+            if (cur.f16) note(hipErrorInvalidValue, "attention block behind fp16 storage");
             Tensor nxt = attention_block(s.at, cur, carry, s.up ? nullptr : out, out_goff, s.track_final && !s.up && h->f16_path());
             if (carry_owned) drop_sink(carry);
             carry_owned = false;
@@ -789,12 +804,12 @@ struct Ctx {
         }
         if (carry_owned) drop_sink(carry);
         if (s.up) {
-            Tensor u = make(s.cout, 2 * H, 2 * W);
+            Tensor u = make(s.cout, 2 * H, 2 * W, lvl16(2 * H) && s.uconv.f2);
             const bool track = s.uconv.f2 && h->f16_path();  // the fp16-operand convolution below needs max|u| < 65504
             ctx = s.name + ".upsample";
-            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? range_site("max|FIR output| (raw input of the up-sampling convolution)") : nullptr), "fir_up2");
+            if (!dry()) note(launch_fir_up2(cur.p, cur.bs(), u.p, u.bs(), B, s.cout, H, W, st, track ? range_site("max|FIR output| (raw input of the up-sampling convolution)") : nullptr, cur.f16, u.f16), "fir_up2");
             drop(cur);
-            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track, s.track_final && h->f16_path());
+            cur = conv(s.uconv, src1(u), 2 * H, 2 * W, PRO_NONE, nullptr, nullptr, 0, false, nullptr, out, out_goff, false, track, s.track_final && h->f16_path(), nullptr, u.f16, u.f16);
             drop(u);
         }
         return cur;
@@ -858,13 +873,34 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     Ctx::Sink s_u2 = k.make_sink(S[6].cin, H / 2, W / 2);
     Ctx::Sink s_u3 = k.make_sink(S[5].cin, H / 4, W / 4);
     Ctx::Sink s_u4 = k.make_sink(S[4].cin, H / 8, W / 8);
+    {
+        // fp16 storage of the full-resolution levels (Ctx::lvl16): the one-plane mode, the default network family (every GroupNorm of levels 1 and 2 on fused
+        // statistics -- the streaming pass reads fp32 --, in_conv on the few-input kernel, FIR statistics at both levels).  R2DM_FP16_STORAGE=1: only between a
+        // residual block's two convolutions (round 5); 0: nowhere.  Read per forward like R2DM_GN_FOLD (ws_cache: r2dm_set_conv_pieces clears it; tests build one
+        // model per setting).
+        const char* e = getenv("R2DM_FP16_STORAGE");
+        const int level = e ? atoi(e) : 2;
+        // ... and every convolution of those levels on a kernel that has the second I/O type (at small batches some layers have too few tiles for conv_f16x2
+        // and run the bf16 kernels: then nothing changes)
+        auto blocks_ok = [](const Stage& st) {
+            for (const ResLayer& r : st.res)
+                if (!r.conv1.f2 || !r.conv2.f2 || (r.has_skip && !r.skip.p1)) return false;
+            return true;
+        };
+        k.all16 = level >= 2 && h->conv_pieces == 1 && G == 8 && c.base_channels % 64 == 0 && h->in_conv.algo == ALGO_DIRECT && h->in_conv.cout > 4 &&
+                  h->out_conv.algo == ALGO_DIRECT && W % 4 == 0 && S[1].down && S[2].down && S[1].dconv.f2 && S[2].dconv.f2 && S[5].up && S[6].up &&
+                  S[5].uconv.f2 && S[6].uconv.f2 && !S[0].attn && !S[1].attn && !S[6].attn && !S[7].attn && blocks_ok(S[0]) && blocks_ok(S[1]) && blocks_ok(S[6]) &&
+                  blocks_ok(S[7]) && S[6].skip_in_bounded && S[7].skip_in_bounded &&
+                  fir_down2_stat_slots(S[1].cout, G, H, W) != 0 && fir_down2_stat_slots(S[2].cout, G, H / 2, W / 2) != 0;
+    }
     k.ctx = "in_conv";
-    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, c.coord_channels ? &cmap_t : nullptr, 0, false, nullptr, &s_d1, 0, /*res_broadcast=*/true);
-    Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2);
+    Tensor h0 = k.conv(h->in_conv, in, H, W, PRO_NONE, nullptr, c.coord_channels ? &cmap_t : nullptr, 0, false, nullptr, &s_d1, 0, /*res_broadcast=*/true, false, false, nullptr,
+                       false, k.lvl16(H) && s_d1.p != nullptr);
+    Tensor h1 = k.stage(S[0], src1(h0), H, W, s_d1, &s_u1, G / 2, false, h0.f16);
     k.drop(h0);
     k.drop_sink(s_d1);
-    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2, S[0].out_tracked && h->f16_path());
-    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2, S[1].out_tracked && h->f16_path());
+    Tensor h2 = k.stage(S[1], src1(h1), H, W, Ctx::Sink{}, &s_u2, G / 2, S[0].out_tracked && h->f16_path(), h1.f16);
+    Tensor h3 = k.stage(S[2], src1(h2), H / 2, W / 2, Ctx::Sink{}, &s_u3, G / 2, S[1].out_tracked && h->f16_path(), h2.f16);
     Tensor h4 = k.stage(S[3], src1(h3), H / 4, W / 4, Ctx::Sink{}, &s_u4, 0, S[2].out_tracked && h->f16_path());
     Tensor u = k.stage(S[4], src1(h4), H / 8, W / 8, s_u4, &s_u3, 0);
     k.drop(h4);
@@ -873,16 +909,18 @@ int run_forward(r2dm_handle* h, Arena& ar, const float* x, const float* cond, fl
     k.drop(u);
     k.drop(h3);
     k.drop_sink(s_u3);
-    Tensor u2 = k.stage(S[6], src2(u3, h2), H / 2, W / 2, s_u2, &s_u1, 0);
+    if (u3.f16 != h2.f16 || h3.f16) k.note(hipErrorInvalidValue, "fp16 storage: the two halves of a skip join differ");
+    Tensor u2 = k.stage(S[6], src2(u3, h2), H / 2, W / 2, s_u2, &s_u1, 0, false, u3.f16 && h2.f16);
     k.drop(u3);
     k.drop(h2);
     k.drop_sink(s_u2);
-    Tensor u1 = k.stage(S[7], src2(u2, h1), H, W, s_u1, nullptr, 0);
+    if (u2.f16 != h1.f16) k.note(hipErrorInvalidValue, "fp16 storage: the two halves of a skip join differ");
+    Tensor u1 = k.stage(S[7], src2(u2, h1), H, W, s_u1, nullptr, 0, false, u2.f16 && h1.f16);
     k.drop(u2);
     k.drop(h1);
     k.drop_sink(s_u1);
     k.ctx = "out_conv";
-    k.conv(h->out_conv, src1(u1), H, W, PRO_NONE, nullptr, nullptr, 0, false, out);
+    k.conv(h->out_conv, src1(u1), H, W, PRO_NONE, nullptr, nullptr, 0, false, out, nullptr, 0, false, false, false, nullptr, u1.f16, false);
     k.drop(u1);
     ar.release(act);
     ar.release(proj);
@@ -1215,6 +1253,12 @@ int64_t r2dm_conv_packed_elems(int32_t cout, int32_t cin, int32_t ksize, int32_t
     return n;
 }
 
+// (per-kernel tests of the fp16 activation storage: R2DM_TEST_IO16 bit 0 -- x holds fp16, bit 1 -- y will; the caller passes tensors of that type)
+static int test_io16() {
+    const char* e = getenv("R2DM_TEST_IO16");
+    return e ? atoi(e) : 0;
+}
+
 int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w_packed, const float* aff,
                      int32_t prologue, const float* residual, const float* scale, float* y, int32_t B, int32_t cin,
                      int32_t cout, int32_t H, int32_t W, int32_t ksize, void* stream) {
@@ -1229,7 +1273,9 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
         p.algo = ALGO_F32;
         p.pieces = g_single_kernel_pieces;
     }
-    if (p.algo == ALGO_DIRECT && (prologue != PRO_NONE || residual || scale || W % 4 != 0)) p.algo = ALGO_F32;  // plain convolutions of 16-byte rows only
+    // (the few-input kernel -- in_conv in the engine -- where the fp16-storage test hook asks for it: plain convolutions only)
+    if (test_io16() && conv_few_in_supported(cin, cout, p.taps, H, W) && prologue == PRO_NONE && !scale) p.algo = ALGO_DIRECT;
+    if (p.algo == ALGO_DIRECT && cout <= 4 && (prologue != PRO_NONE || residual || scale || W % 4 != 0)) p.algo = ALGO_F32;  // plain convolutions of 16-byte rows only
                                                                                                              // (any other width runs on the fp32-MFMA kernel)
     // per-op tests: with pieces = 2 every shape the f16x2 kernel covers goes there (the engine restricts it to normalised inputs)
     if (p.algo == ALGO_BF16X3 && g_single_kernel_pieces != 3 && conv_f16x2_supported(cin, cout, p.taps, H, W)) p.algo = ALGO_F16X2;
@@ -1267,8 +1313,10 @@ int r2dm_conv2d_ring(const float* x, const float* w, const float* bias, float* w
     p.prologue = prologue;
     // per-kernel tests of the fp16 activation storage (conv_f16x2.hip, one-plane mode): R2DM_TEST_IO16 = 1 (x holds fp16), 2 (y and the
     // residual hold fp16) or 3 -- the caller passes tensors of that type behind the float pointers
-    if (const char* e = getenv("R2DM_TEST_IO16"); e && p.algo == ALGO_F16X2 && p.pieces == 1) {
-        p.x16 = atoi(e) & 1;
+    if (const char* e = getenv("R2DM_TEST_IO16"); e && (atoi(e) & 3)) {  // (bit 2 alone: only the kernel selection above -- the fp32 twin of a storage test)
+        if (!((p.algo == ALGO_F16X2 && p.pieces == 1) || p.algo == ALGO_DIRECT || (p.algo == ALGO_P1F16 && p.pieces == 1)))
+            return fail(1, "R2DM_TEST_IO16: this shape / mode runs on a kernel without fp16 storage");  // (never write a type the caller did not allocate)
+        p.x16 = atoi(e) & 1;  // (round 6: also the in / out convolutions -- bit 1 / bit 0 -- and, with both bits, the fp16-operand 1 x 1 convolution)
         p.y16 = (atoi(e) >> 1) & 1;
     }
     // perf probe (scripts/conv_phases.py): per-block s_memtime stamps into a caller-provided device buffer
@@ -1315,7 +1363,7 @@ int r2dm_affine_act(const float* x, const float* aff, float* y, int32_t B, int32
 }
 
 int r2dm_fir_down2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
-    HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream));
+    HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream, nullptr, 0, test_io16() & 1, (test_io16() >> 1) & 1));
     return 0;
 }
 
@@ -1325,12 +1373,12 @@ int32_t r2dm_fir_down2_stat_slots(int32_t C, int32_t G, int32_t H, int32_t W) {
 
 int r2dm_fir_down2_stats(const float* x, float* y, double* stat, int32_t B, int32_t C, int32_t G, int32_t H, int32_t W, void* stream) {
     if (!stat || !fir_down2_stat_slots(C, G, H, W)) return fail(1, "fir_down2_stats: geometry without a statistics variant");
-    HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream, stat, G));
+    HIP_TRY(launch_fir_down2(x, (long)C * H * W, y, (long)C * (H / 2) * (W / 2), B, C, H, W, (hipStream_t)stream, stat, G, test_io16() & 1, (test_io16() >> 1) & 1));
     return 0;
 }
 
 int r2dm_fir_up2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
-    HIP_TRY(launch_fir_up2(x, (long)C * H * W, y, (long)C * H * W * 4, B, C, H, W, (hipStream_t)stream));
+    HIP_TRY(launch_fir_up2(x, (long)C * H * W, y, (long)C * H * W * 4, B, C, H, W, (hipStream_t)stream, nullptr, test_io16() & 1, (test_io16() >> 1) & 1));
     return 0;
 }
 

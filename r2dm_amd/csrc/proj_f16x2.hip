@@ -36,8 +36,9 @@ constexpr int LDS_TOTAL = PATCH0 + 4 * 1024;  // 55 296
 
 // NPLK = operand planes in use: 2 = the split arithmetic (parity path), 1 = the h plane alone: one fp16 product per MAC, the
 // reduced-precision bulk mode (conv_f16x2.hip); the l planes are then neither written nor read.
-template <int PRO, int NPLK>
+template <int PRO, int NPLK, int IOM = 0>
 __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) {
+    constexpr bool X16 = (IOM & 1) != 0, Y16 = (IOM & 2) != 0;  // (round 6) fp16 storage of the input tensor(s) / of the output (+ residual): the one-plane mode's skip convolutions
     using namespace p1;
     using gcf4 = const f32x4 __attribute__((address_space(1)))*;
     using gcu4 = const u32x4 __attribute__((address_space(1)))*;
@@ -69,9 +70,16 @@ __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) 
     u32x4 wv[2];
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int ch = c * CKP + cg * 8;
+        if constexpr (X16) {  // (element offsets: load4 addresses halves)
+            const float* px = ch < c0 ? p.x.p0 : p.x.p1;
+            const long e0 = (ch < c0 ? b * p.x.bs0 + (long)ch * HW : b * p.x.bs1 + (long)(ch - c0) * HW) + poff;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = load4<true>(px, e0 + (long)i * HW);
+        } else {
         const float* pl = ch < c0 ? xb0 + (long)ch * HW : xb1 + (long)(ch - c0) * HW;
 #pragma unroll
         for (int i = 0; i < 8; ++i) raw[i] = *(gcf4)(pl + (long)i * HW + poff);
+        }
         if (PRO != PRO_NONE) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) ad4[j] = *(gcf4)(affb + (size_t)(ch + 2 * j) * 2);
@@ -156,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void proj_f16x2_kernel(const ConvParams p) 
                                                    reinterpret_cast<float*>(smem + PATCH0) + wave * 256, f2::LINV, wsc);
     } else {
         f32x16 none[1][1];
-        conv_epilogue_wide<TH, TW, MR, NR, false>(p, acc, none, b, th, tw, nTw, cot * CO_T, wave, lane,
-                                                    reinterpret_cast<float*>(smem + PATCH0) + wave * 256, 1.0f, wsc);
+        conv_epilogue_wide<TH, TW, MR, NR, false, Y16>(p, acc, none, b, th, tw, nTw, cot * CO_T, wave, lane,
+                                                         reinterpret_cast<float*>(smem + PATCH0) + wave * 256, 1.0f, wsc);
     }
 }
 
@@ -367,9 +375,9 @@ static hipError_t launch_p1_tall(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int PRO, int NPLK>
+template <int PRO, int NPLK, int IOM = 0>
 static hipError_t launch_p1(const ConvParams& p, hipStream_t s) {
-    auto kern = proj_f16x2_kernel<PRO, NPLK>;
+    auto kern = proj_f16x2_kernel<PRO, NPLK, IOM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, p1::LDS_TOTAL);
@@ -386,6 +394,10 @@ hipError_t launch_proj_f16x2(const ConvParams& p, hipStream_t s) {
     if (p.x.p1 && p.x.c0 % 8) return hipErrorInvalidValue;  // a thread's 8 channels must not straddle the concat seam
     if (p.prologue == PRO_AFFINE_SILU || (p.prologue != PRO_NONE && p.aff == nullptr)) return hipErrorInvalidValue;
     if (p.stat && p.stat_slots != conv_stat_slots(p.H, p.W)) return hipErrorInvalidValue;
+    if (p.x16 || p.y16) {  // fp16 storage (round 6): the skip convolutions of the full-resolution levels in the one-plane mode -- raw fp16 input, fp16 output
+        if (!(p.x16 && p.y16) || p.pieces != 1 || p.prologue != PRO_NONE || p.res || p.stat) return hipErrorInvalidValue;
+        return launch_p1<PRO_NONE, 1, 3>(p, s);
+    }
     static const bool tall_on = getenv("R2DM_PROJ_TALL") == nullptr || atoi(getenv("R2DM_PROJ_TALL")) != 0;  // (0: experiments)
     if (tall_on && p.Cout % p1::COB == 0) {  // 256-channel blocks: every pixel staged Cout / 256 times instead of Cout / 64
         if (p.pieces == 1) return p.prologue == PRO_NONE ? launch_p1_tall<PRO_NONE, 1>(p, s) : launch_p1_tall<PRO_AFFINE, 1>(p, s);

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void fir_down2_any_kernel(const float* __restr
 // loads per row -- 12 of the 24 load instructions of a patch, the ones that cost the CU's address pipeline a whole wave-wide request for 4 bytes per
 // lane.  Valid where a wave's lanes hold consecutive column quads of whole rows (Wq = W / 8 divides 64 and lane % Wq == t: launcher); the wrap of the
 // azimuth is then a lane rotation inside the row's Wq lanes.  Same operands into the same fir4 chain: bit-identical outputs.
-template <int SHFL>  // 0: halo columns by loads | 1: lane rotation inside the row's Wq lanes (Wq divides 64) | 2: lanes +-1, a wave's edge lanes load (Wq a multiple of 64)
-__device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, int H, int W, int i2, int t, f32x4 (&v)[2], int lane = 0, int Wq = 0) {
+// X16 (round 6): the input is stored as fp16 (the one-plane mode's activation storage at the full-resolution levels); xp + e0: the input plane
+template <int SHFL, bool X16 = false>  // SHFL 0: halo columns by loads | 1: lane rotation inside the row's Wq lanes (Wq divides 64) | 2: lanes +-1, a wave's edge lanes load (Wq a multiple of 64)
+__device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, long e0, int H, int W, int i2, int t, f32x4 (&v)[2], int lane = 0, int Wq = 0) {
     const int cl = 8 * t - 1 < 0 ? W - 1 : 8 * t - 1;
     const int cr = 8 * t + 8 >= W ? 0 : 8 * t + 8;
     // (SHFL) byte addresses of the lanes holding column quads t - 1 and t + 1 of this row (Wq is a power of two here)
@@ -101,26 +102,25 @@ __device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, in
         if constexpr (SHFL != 0) {
             f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
             if (in) {
-                const float* row = xp + (long)r * W;
-                m0 = *reinterpret_cast<const f32x4*>(row + 8 * t);
-                m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
+                m0 = load4<X16>(xp, e0 + (long)r * W + 8 * t);
+                m1 = load4<X16>(xp, e0 + (long)r * W + 8 * t + 4);
             }
             // (all lanes take part in the exchange; lanes of another row pair may be outside the image while this one is inside: their values are
             // not read by anybody of this row)
             float l = __int_as_float(__builtin_amdgcn_ds_bpermute(lsrc, __float_as_int(m1[3])));
             float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(rsrc, __float_as_int(m0[0])));
             if constexpr (SHFL == 2) {  // (lane % 64 == t % 64: the first and last lane of a wave have their neighbour in another wave -- or across the seam)
-                if (in && lane == 0) l = (xp + (long)r * W)[cl];
-                if (in && lane == 63) rr = (xp + (long)r * W)[cr];
+                if (in && lane == 0) l = load1<X16>(xp, e0 + (long)r * W + cl);
+                if (in && lane == 63) rr = load1<X16>(xp, e0 + (long)r * W + cr);
             }
             h[a][0] = in ? fir4(l, m0[0], m0[1], m0[2]) : 0.f;
             h[a][1] = in ? fir4(m0[1], m0[2], m0[3], m1[0]) : 0.f;
             h[a][2] = in ? fir4(m0[3], m1[0], m1[1], m1[2]) : 0.f;
             h[a][3] = in ? fir4(m1[1], m1[2], m1[3], rr) : 0.f;
         } else if (in) {
-            const float* row = xp + (long)r * W;
-            const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + 8 * t), m1 = *reinterpret_cast<const f32x4*>(row + 8 * t + 4);
-            const float l = row[cl], rr = row[cr];
+            const long er = e0 + (long)r * W;
+            const f32x4 m0 = load4<X16>(xp, er + 8 * t), m1 = load4<X16>(xp, er + 8 * t + 4);
+            const float l = load1<X16>(xp, er + cl), rr = load1<X16>(xp, er + cr);
             h[a][0] = fir4(l, m0[0], m0[1], m0[2]);
             h[a][1] = fir4(m0[1], m0[2], m0[3], m1[0]);
             h[a][2] = fir4(m0[3], m1[0], m1[1], m1[2]);
@@ -136,7 +136,7 @@ __device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, in
         for (int j = 0; j < 4; ++j) v[o][j] = fir4(h[2 * o][j], h[2 * o + 1][j], h[2 * o + 2][j], h[2 * o + 3][j]);
 }
 
-template <int SHFL>
+template <int SHFL, bool X16 = false, bool Y16 = false>
 __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                              long ybs, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1, Wq = Wo >> 2, Hq = Ho >> 1;  // Wq threads per pair of output rows
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __rest
         const long rem = idx % per_plane;
         const int i2 = rem / Wq, t = rem % Wq;
         f32x4 v[2];
-        fir_down2_patch<SHFL>(x + b * xbs + (long)c * H * W, H, W, i2, t, v, (int)threadIdx.x & 63, Wq);
+        fir_down2_patch<SHFL, X16>(x, b * xbs + (long)c * H * W, H, W, i2, t, v, (int)threadIdx.x & 63, Wq);
 #pragma unroll
-        for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v[o];
+        for (int o = 0; o < 2; ++o) store4<Y16>(y, b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t, v[o]);
     }
 }
 
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void fir_down2_wide_kernel(const float* __rest
 // column quad), lane L the patches L, L + 64, ...; fp64 from the first addition, one wave total per slot: fixed order, every slot
 // written exactly once per launch.  Groups of fewer than 64 channels use half 0 and zero half 1 (as the epilogues do); a
 // 64-channel group uses all 2 S slots.
-template <int SHFL>
+template <int SHFL, bool X16 = false, bool Y16 = false>
 __global__ __launch_bounds__(256) void fir_down2_stats_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y, long ybs,
                                                               int cpg, int H, int W, int ipw, double* __restrict__ stat, int slots) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -176,13 +176,13 @@ __global__ __launch_bounds__(256) void fir_down2_stats_kernel(const float* __res
         const int c = g * cpg + cg;
         const int i2 = rem / Wq, t = rem - i2 * Wq;
         f32x4 v[2];
-        fir_down2_patch<SHFL>(x + b * xbs + (long)c * H * W, H, W, i2, t, v, lane, Wq);
+        fir_down2_patch<SHFL, X16>(x, b * xbs + (long)c * H * W, H, W, i2, t, v, lane, Wq);
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            *reinterpret_cast<f32x4*>(y + b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t) = v[o];
+            const f32x4 st = store4<Y16>(y, b * ybs + (long)c * Ho * Wo + (long)(2 * i2 + o) * Wo + 4 * t, v[o]);  // (the statistics are those of the STORED values)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const double d = (double)v[o][e];
+                const double d = (double)st[e];
                 s += d;
                 q = fma(d, d, q);
             }
@@ -208,6 +208,7 @@ __device__ __forceinline__ float up1(float far, float near) { return __builtin_f
 // one thread -> input columns 2t, 2t+1 of row i -> a 2x4 output patch
 // range (optional): the running maximum of |output| is merged into range[1] as float bits (positive floats order like their
 // bit patterns) -- the f16x2 convolution that consumes this tensor needs it below 65504 (engine.hip, r2dm_check_range)
+template <bool X16 = false, bool Y16 = false>  // (round 6) fp16 storage of the input / the output; the running maximum is that of the STORED values
 __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                       long ybs, int C, int H, int W, int* __restrict__ range) {
     float amax = 0.f;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         const int c = idx / per_plane;
         const long rem = idx % per_plane;
         const int i = rem / Wh, t = rem % Wh;
-        const float* xp = x + b * xbs + (long)c * H * W;
+        const long e0 = b * xbs + (long)c * H * W;
         const int cl = 2 * t - 1 < 0 ? W - 1 : 2 * t - 1;
         const int cr = 2 * t + 2 >= W ? 0 : 2 * t + 2;
         float h[3][4];  // horizontally upsampled rows i-1, i, i+1 at output columns 4t..4t+3
@@ -227,9 +228,11 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         for (int a = 0; a < 3; ++a) {
             const int r = i + a - 1;
             if (r >= 0 && r < H) {
-                const float* row = xp + (long)r * W;
-                const float2 m = *reinterpret_cast<const float2*>(row + 2 * t);
-                const float l = row[cl], rr = row[cr];
+                const long er = e0 + (long)r * W;
+                float2 m;
+                if constexpr (X16) m = make_float2(load1<true>(x, er + 2 * t), load1<true>(x, er + 2 * t + 1));
+                else m = *reinterpret_cast<const float2*>(x + er + 2 * t);
+                const float l = load1<X16>(x, er + cl), rr = load1<X16>(x, er + cr);
                 h[a][0] = up1(l, m.x);
                 h[a][1] = up1(m.y, m.x);
                 h[a][2] = up1(m.x, m.y);
@@ -244,12 +247,11 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
             e[j] = up1(h[0][j], h[1][j]);
             o[j] = up1(h[2][j], h[1][j]);
         }
-        float* out = y + b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 4 * t;
-        *reinterpret_cast<f32x4*>(out) = e;
-        *reinterpret_cast<f32x4*>(out + Wo) = o;
+        const long eo = b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 4 * t;
+        const f32x4 es = store4<Y16>(y, eo, e), os = store4<Y16>(y, eo + Wo, o);
         if (range) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(e[j]), fabsf(o[j])));
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(es[j]), fabsf(os[j])));
         }
     }
     if (range) {
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
 // stores and is bound by the CU's address pipeline (4.2 TB/s).  Lanes at a wave's edge or at the azimuth seam load their halo (one or two lanes of a masked
 // instruction).  The same chains (up1) on the same operands: bit-identical to the kernel above.
 
+template <bool X16 = false, bool Y16 = false>
 __global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                            long ybs, int C, int H, int W, int* __restrict__ range) {
     float amax = 0.f;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restri
         const int c = idx / per_plane;
         const long rem = idx % per_plane;
         const int i = rem / Wt, t = rem % Wt;
-        const float* xp = x + b * xbs + (long)c * H * W;
+        const long e0 = b * xbs + (long)c * H * W;
         // the lanes to the left / right hold the neighbouring quads of the same row unless this lane is first / last in its wave or in its row
         // (a partial last wave: its active lanes are the low ones, and total is a multiple of Wt -- a right neighbour in the same row is active)
         const bool lsh = lane > 0 && t > 0, rsh = lane < 63 && t < Wt - 1;
@@ -288,12 +291,12 @@ __global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restri
         for (int a = 0; a < 3; ++a) {
             const int r = i + a - 1;
             const bool in = r >= 0 && r < H;  // (rows i-1 / i+1 of lanes in other rows of the wave may differ: every lane takes part in the exchange)
-            const float* row = xp + (long)(in ? r : i) * W;
-            const f32x4 m = *reinterpret_cast<const f32x4*>(row + 4 * t);
+            const long er = e0 + (long)(in ? r : i) * W;
+            const f32x4 m = load4<X16>(x, er + 4 * t);
             float l = __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 1) << 2, __float_as_int(m[3])));
             float rr = __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) << 2, __float_as_int(m[0])));
-            if (!lsh) l = row[cl];
-            if (!rsh) rr = row[cr];
+            if (!lsh) l = load1<X16>(x, er + cl);
+            if (!rsh) rr = load1<X16>(x, er + cr);
             h[a][0] = in ? up1(l, m[0]) : 0.f;
             h[a][1] = in ? up1(m[1], m[0]) : 0.f;
             h[a][2] = in ? up1(m[0], m[1]) : 0.f;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restri
             h[a][6] = in ? up1(m[2], m[3]) : 0.f;
             h[a][7] = in ? up1(rr, m[3]) : 0.f;
         }
-        float* out = y + b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 8 * t;
+        const long eo = b * ybs + (long)c * (4L * H * W) + (long)(2 * i) * Wo + 8 * t;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             f32x4 e, o;
@@ -312,12 +315,9 @@ __global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restri
                 e[j] = up1(h[0][4 * q + j], h[1][4 * q + j]);
                 o[j] = up1(h[2][4 * q + j], h[1][4 * q + j]);
             }
-            *reinterpret_cast<f32x4*>(out + 4 * q) = e;
-            *reinterpret_cast<f32x4*>(out + Wo + 4 * q) = o;
-            if (range) {
+            const f32x4 es = store4<Y16>(y, eo + 4 * q, e), os = store4<Y16>(y, eo + Wo + 4 * q, o);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(e[j]), fabsf(o[j])));
-            }
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(es[j]), fabsf(os[j])));  // (unconditional: only merged into the flag if `range`)
         }
     }
     if (range) {
@@ -358,8 +358,32 @@ static int shfl_mode(int W) {
     return Wq <= 64 && 64 % Wq == 0 ? 1 : Wq % 64 == 0 ? 2 : 0;  // (whole rows inside a wave | whole waves inside a row)
 }
 
-hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, double* stat, int G) {
+hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, double* stat, int G, int x16, int y16) {
     if ((W & 1) || (H & 1)) return hipErrorInvalidValue;
+    if (y16 && !x16) return hipErrorInvalidValue;  // (fp16 storage, round 6: fp16 -> fp16 between the full-resolution levels, fp16 -> fp32 below them)
+    if (x16) {  // the kernels of the engine's geometries only (W % 8 == 0, H % 4 == 0)
+        if (W % 8 || H % 4) return hipErrorInvalidValue;
+        const int sm = shfl_mode(W);
+        if (stat) {
+            const int used = fir_down2_stat_slots(C, G, H, W);
+            if (!used) return hipErrorInvalidValue;
+            const int cpg = C / G;
+            const int ipw = (int)((long)cpg * (H / 4) * (W / 8) / used);
+            const dim3 grid(used / 4, G, B);
+            const int slots = conv_stat_slots(H / 2, W / 2);
+#define R2DM_FDS(SM, Y) fir_down2_stats_kernel<SM, true, Y><<<grid, 256, 0, s>>>(x, xbs, y, ybs, cpg, H, W, ipw, stat, slots)
+            if (y16) { if (sm == 1) R2DM_FDS(1, true); else if (sm == 2) R2DM_FDS(2, true); else R2DM_FDS(0, true); }
+            else { if (sm == 1) R2DM_FDS(1, false); else if (sm == 2) R2DM_FDS(2, false); else R2DM_FDS(0, false); }
+#undef R2DM_FDS
+            return hipGetLastError();
+        }
+        const dim3 grid(grid_for((long)C * (H / 4) * (W / 8)), B);
+#define R2DM_FDW(SM, Y) fir_down2_wide_kernel<SM, true, Y><<<grid, 256, 0, s>>>(x, xbs, y, ybs, C, H, W)
+        if (y16) { if (sm == 1) R2DM_FDW(1, true); else if (sm == 2) R2DM_FDW(2, true); else R2DM_FDW(0, true); }
+        else { if (sm == 1) R2DM_FDW(1, false); else if (sm == 2) R2DM_FDW(2, false); else R2DM_FDW(0, false); }
+#undef R2DM_FDW
+        return hipGetLastError();
+    }
     if (W & 3) {  // (never inside the engine: its widths are multiples of 32)
         if (stat) return hipErrorInvalidValue;
         fir_down2_any_kernel<<<dim3(grid_for((long)C * (H / 2) * (W / 2)), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W);
@@ -391,9 +415,22 @@ hipError_t launch_fir_down2(const float* x, long xbs, float* y, long ybs, int B,
     return hipGetLastError();
 }
 
-hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, int* range) {
+hipError_t launch_fir_up2(const float* x, long xbs, float* y, long ybs, int B, int C, int H, int W, hipStream_t s, int* range, int x16, int y16) {
     if (W & 1) return hipErrorInvalidValue;
+    if (x16 && !y16) return hipErrorInvalidValue;  // (fp16 storage, round 6: fp32 -> fp16 into the full-resolution levels, fp16 -> fp16 between them)
     const char* e = getenv("R2DM_FIR_UP_WIDE");  // (0: the two-column kernel, as until round 5; 2: the wide kernel at any size -- A/B, tests; read per call)
+    if (y16) {
+        const bool wide = W % 4 == 0 && !(e && atoi(e) == 0) && ((long)B * C * H * W >= (8L << 20) || (e && atoi(e) == 2));
+        const dim3 grid(grid_for(wide ? (long)C * H * (W / 4) : (long)C * H * (W / 2)), B);
+        if (wide) {
+            if (x16) fir_up2_wide_kernel<true, true><<<grid, 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
+            else fir_up2_wide_kernel<false, true><<<grid, 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
+        } else {
+            if (x16) fir_up2_kernel<true, true><<<grid, 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
+            else fir_up2_kernel<false, true><<<grid, 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);
+        }
+        return hipGetLastError();
+    }
     // (small maps stay on the two-column kernel: with a quarter of the threads the wide one is latency-bound -- 256 channels of 8 x 128 at batch 8: 18 -> 22 us)
     if (W % 4 == 0 && !(e && atoi(e) == 0) && ((long)B * C * H * W >= (8L << 20) || (e && atoi(e) == 2))) {
         fir_up2_wide_kernel<<<dim3(grid_for((long)C * H * (W / 4)), B), 256, 0, s>>>(x, xbs, y, ybs, C, H, W, range);

@@ -54,31 +54,39 @@ def affine_act(x, aff, silu):
     return y
 
 
-def fir_down2(x):
+def _io(x, io16):
+    return x.detach().half().contiguous() if io16 & 1 else _lib.f32c(x)
+
+
+def fir_down2(x, io16=0):
+    """io16 (with R2DM_TEST_IO16 set to the same value by the caller): bit 0 -- x as a half tensor, bit 1 -- y will be one."""
     B, C, H, W = x.shape
-    y = torch.empty(B, C, H // 2, W // 2, device=x.device)
+    x = _io(x, io16)
+    y = torch.empty(B, C, H // 2, W // 2, device=x.device, dtype=torch.float16 if io16 & 2 else torch.float32)
     _lib.check(_lib.lib().r2dm_fir_down2(x.data_ptr(), y.data_ptr(), B, C, H, W, _st(x)))
     torch.cuda.synchronize()
     return y
 
 
-def fir_down2_stats(x, groups):
+def fir_down2_stats(x, groups, io16=0):
     """(y, stat): ops.Resample(down=2) plus the GroupNorm statistics of y as the engine's path leaves them -- stat (B, groups, slots, 2)
     float64 [sum, sum of squares]; None where the geometry has no statistics variant."""
     B, C, H, W = x.shape
     slots = _lib.lib().r2dm_fir_down2_stat_slots(C, groups, H, W)
     if slots == 0:
         return None
-    y = torch.empty(B, C, H // 2, W // 2, device=x.device)
+    x = _io(x, io16)
+    y = torch.empty(B, C, H // 2, W // 2, device=x.device, dtype=torch.float16 if io16 & 2 else torch.float32)
     stat = torch.full((B, groups, slots, 2), float("nan"), device=x.device, dtype=torch.float64)
     _lib.check(_lib.lib().r2dm_fir_down2_stats(x.data_ptr(), y.data_ptr(), stat.data_ptr(), B, C, groups, H, W, _st(x)))
     torch.cuda.synchronize()
     return y, stat
 
 
-def fir_up2(x):
+def fir_up2(x, io16=0):
     B, C, H, W = x.shape
-    y = torch.empty(B, C, H * 2, W * 2, device=x.device)
+    x = _io(x, io16)
+    y = torch.empty(B, C, H * 2, W * 2, device=x.device, dtype=torch.float16 if io16 & 2 else torch.float32)
     _lib.check(_lib.lib().r2dm_fir_up2(x.data_ptr(), y.data_ptr(), B, C, H, W, _st(x)))
     torch.cuda.synchronize()
     return y

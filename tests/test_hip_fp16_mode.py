@@ -123,6 +123,113 @@ def test_conv_fp16_storage_is_exact(H, cin, cout, h, w, tile):
     assert torch.equal(out[2], out[0].half()) and torch.equal(out[3], out[0].half())  # fp16 output: the fp32 result, rounded once
 
 
+class _io16:
+    """R2DM_TEST_IO16 for the duration of a block (the single-kernel C entries read it per call)."""
+
+    def __init__(self, v):
+        self.v = str(v)
+
+    def __enter__(self):
+        import os
+        self.saved = os.environ.get("R2DM_TEST_IO16")
+        os.environ["R2DM_TEST_IO16"] = self.v
+
+    def __exit__(self, *a):
+        import os
+        os.environ.pop("R2DM_TEST_IO16", None)
+        if self.saved is not None:
+            os.environ["R2DM_TEST_IO16"] = self.saved
+
+
+@pytest.mark.parametrize("C,h,w,groups", [(128, 64, 1024, 8), (256, 32, 512, 8), (16, 8, 64, 0)])
+def test_fir_resamplers_fp16_storage_is_exact(H, C, h, w, groups):
+    """Round 6: the activations of the two full-resolution levels are stored as fp16 in the one-plane mode -- the FIR resamplers'
+    second I/O type.  Storage is the ONLY change: on fp16-representable inputs a launch reading fp16 equals the launch reading the same values as fp32 bit
+    for bit, a launch writing fp16 equals RNE_f16 of the fp32 launch (both wave-exchange modes of the down-sampler, both up-sampler kernels), and the fused
+    GroupNorm statistics are those of the STORED values."""
+    B = 2
+    x = (rnd(5, B, C, h, w) * 1.3 + 0.2).half().float().to(DEV)
+    d32, u32 = H.fir_down2(x), H.fir_up2(x)
+    with _io16(1):
+        assert torch.equal(H.fir_down2(x, io16=1), d32)            # fp16 in, fp32 out (level 2 -> 3)
+    with _io16(3):
+        assert torch.equal(H.fir_down2(x, io16=3), d32.half())     # fp16 in, fp16 out (level 1 -> 2)
+        assert torch.equal(H.fir_up2(x, io16=3), u32.half())       # (level 2 -> 1)
+    with _io16(2):
+        assert torch.equal(H.fir_up2(x, io16=2), u32.half())       # fp32 in, fp16 out (level 3 -> 2)
+    if groups:
+        with _io16(3):
+            y, stat = H.fir_down2_stats(x, groups, io16=3)
+        assert torch.equal(y, d32.half())
+        yd = y.double().reshape(B, groups, -1)
+        got = stat.sum(2)
+        assert ((got[..., 0] - yd.sum(-1)).abs() <= 1e-12 * yd.abs().sum(-1)).all() and ((got[..., 1] - (yd * yd).sum(-1)).abs() <= 1e-12 * (yd * yd).sum(-1)).all()
+        with _io16(1):
+            y1, stat1 = H.fir_down2_stats(x, groups, io16=1)
+        y0, stat0 = H.fir_down2_stats(x, groups)
+        assert torch.equal(y1, y0) and torch.equal(stat1, stat0)
+
+
+def test_in_out_and_skip_convolutions_fp16_storage_is_exact(H):
+    """... and the other kernels of those levels: in_conv (few inputs: fp16 OUTPUT + statistics of the stored values through the engine), out_conv (fp16
+    INPUT) and the fp16-operand 1 x 1 skip convolution (fp16 in and out).  Same contract as the FIR kernels and conv_f16x2's IOM template."""
+    B, h, w = 2, 16, 256
+    H.set_conv_pieces(1)
+    try:
+        # in_conv: 2 -> 64 (+ a residual map, the engine's constant coordinate term)
+        x, wt, b = rnd(1, B, 2, h, w), rnd(2, 64, 2, 3, 3) / math.sqrt(18), rnd(3, 64)
+        with _io16(4):  # (bit 2: the engine's few-input kernel, fp32 in and out -- the twin the fp16 launch is compared with)
+            y32 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV))
+        with _io16(2):
+            y16 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), io16=2)
+        assert y16.dtype == torch.float16 and torch.equal(y16, y32.half())
+        # out_conv: 64 -> 2
+        x, wt, b = rnd(4, B, 64, h, w).half().float(), rnd(5, 2, 64, 3, 3) / math.sqrt(9 * 64), rnd(6, 2)
+        y32 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV))
+        with _io16(1):
+            y1 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), io16=1)
+        assert y1.dtype == torch.float32 and torch.equal(y1, y32)
+        # skip convolution: 128 -> 64, 1 x 1, raw input
+        x, wt, b = rnd(7, B, 128, h, w).half().float(), rnd(8, 64, 128, 1, 1) / math.sqrt(128), rnd(9, 64)
+        y32 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV))
+        with _io16(3):
+            y3 = H.conv2d_ring(x.to(DEV), wt.to(DEV), b.to(DEV), io16=3)
+        assert y3.dtype == torch.float16 and torch.equal(y3, y32.half())
+    finally:
+        H.set_conv_pieces(2)
+
+
+def test_unet_fp16_storage_levels(O):
+    """The whole denoiser with every activation of levels 1 and 2 stored as fp16 (default in the one-plane mode) against the same mode storing fp16 only
+    between a residual block's two convolutions (R2DM_FP16_STORAGE=1, round 5) and fp32 everywhere (0): all three inside the mode's tolerance class against
+    the fp64 oracle, and within a few fp16 roundings of each other."""
+    import os
+
+    import r2dm_amd
+
+    ck = synthetic_ckpt()
+    x, c = rnd(70, 2, 2, 64, 1024).to(DEV), torch.tensor([-3.0, 2.0], device=DEV)
+    sd = {k: v.double().to(DEV) for k, v in O.strip_prefix(ck["ema_weights"]).items()}
+    truth = O.unet_forward(sd, O.UNetConfig(), x.double(), c.double()).cpu()
+    saved = os.environ.get("R2DM_FP16_STORAGE")
+    ys = {}
+    try:
+        for lvl in ("2", "1", "0"):
+            os.environ["R2DM_FP16_STORAGE"] = lvl
+            m, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=2, precision="fp16")
+            ys[lvl] = m.model(x, c).cpu()
+            assert torch.equal(ys[lvl], m.model(x, c).cpu())
+            del m
+    finally:
+        os.environ.pop("R2DM_FP16_STORAGE", None)
+        if saved is not None:
+            os.environ["R2DM_FP16_STORAGE"] = saved
+    e = {k: rel_rms(v, truth) for k, v in ys.items()}
+    print(f"fp16 mode vs fp64, storage levels 2 / 1 / 0: rel rms {e['2']:.2e} {e['1']:.2e} {e['0']:.2e}; level 2 vs level 0: {rel_rms(ys['2'], ys['0'].double()):.2e}")
+    assert all(2e-4 < v < 3e-3 for v in e.values())
+    assert not torch.equal(ys["2"], ys["1"]) and rel_rms(ys["2"], ys["0"].double()) < 2e-3
+
+
 @pytest.mark.parametrize("pro", [1, 2])
 def test_conv_one_product_with_fused_prologue(O, H, pro):
     import torch.nn.functional as F

@@ -76,23 +76,16 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
 #endif
 #pragma unroll DC_UNROLL
     for (int ci = 0; ci < p.Cin; ++ci) {
+        // (the fp32 path is round 5's code to the letter: restructured around a shared loop body it compiled to 72 instead of 122 registers -- fewer loads in
+        // flight -- and took 117 instead of 53 us)
+        const gcf pl = (gcf)(ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW);
+        const float* plx = ci < c0 ? xb0 : xb1;  // (fp16 input: element offsets -- load4 / load1 address halves)
+        const long e0 = (long)(ci < c0 ? ci : ci - c0) * HW;
         float x[R + 2][6];
 #pragma unroll
         for (int k = 0; k < R + 2; ++k) {
-            f32x4 v;
-            float l, r;
-            if constexpr (X16) {  // (batch strides and plane offsets are in ELEMENTS: load4 / load1 address halves)
-                const float* plx = ci < c0 ? xb0 : xb1;
-                const long e0 = (long)(ci < c0 ? ci : ci - c0) * HW + rbase[k];
-                v = load4<true>(plx, e0 + gc);
-                l = load1<true>(plx, e0 + cl);
-                r = load1<true>(plx, e0 + cr);
-            } else {
-                const gcf pl = (gcf)(ci < c0 ? xb0 + (long)ci * HW : xb1 + (long)(ci - c0) * HW);
-                v = *(gcf4)(pl + rbase[k] + gc);
-                l = pl[rbase[k] + cl];
-                r = pl[rbase[k] + cr];
-            }
+            const f32x4 v = X16 ? load4<X16>(plx, e0 + rbase[k] + gc) : *(gcf4)(pl + rbase[k] + gc);
+            const float l = X16 ? load1<X16>(plx, e0 + rbase[k] + cl) : pl[rbase[k] + cl], r = X16 ? load1<X16>(plx, e0 + rbase[k] + cr) : pl[rbase[k] + cr];
             x[k][0] = rok[k] ? l : 0.f;
             x[k][5] = rok[k] ? r : 0.f;
 #pragma unroll

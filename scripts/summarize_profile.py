@@ -70,7 +70,7 @@ out.append("=> HBM-side traffic %.0f-%.0f MB per launch: no wasted re-reads (hal
 # ---- memory-bound kernels: achieved HBM GB/s from the kernel trace (config 1 shapes, batch 8: bytes per step by construction)
 MB = {  # kernel substring -> (algorithmic MB per step, what)
     'fir_down2': (587.2, "3 launches: 128ch@64x1024, 256ch@32x512, 512ch@16x256 read + quarter-size write"),
-    'fir_up2_kernel': (293.6, "3 launches: 256ch@8x128, 128ch@16x256, 64ch@32x512 read + 4x write"),
+    'fir_up2': (293.6, "3 launches: 256ch@8x128, 128ch@16x256, 64ch@32x512 read + 4x write"),
     'gn_partial_kernel': (117.4, "3 launches (statistics of the three FIR-down outputs): one read"),
     'posterior_kernel': (16.8, "1 launch: x_t, prediction, noise read + x_s written, 8x2x64x1024 fp32 each"),
 }

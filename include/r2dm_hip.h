@@ -102,7 +102,8 @@ int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
 
 /* Waits for `stream` and returns non-zero (r2dm_last_error explains) if, since the last call, a forward of `h` ran an
  * f16x2 convolution on operands that may have left the fp16 range -- its output is then not valid.  The Python wrapper
- * calls this after every stand-alone forward and once at the end of a sampling loop. */
+ * calls this after every stand-alone forward and once at the end of a sampling loop.  The recorded bounds are running maxima: a clean check leaves
+ * them (nothing can have tripped unnoticed), a reported trip resets them. */
 int r2dm_check_range(r2dm_handle* h, void* stream);
 
 /* Per-site view of the guard (round 6; python -m r2dm_amd.check): a SITE is one guarded producer of a forward in walk order -- a GroupNorm's

@@ -391,7 +391,8 @@ struct Ctx {
     int n_sites = 0;
     std::string ctx;
     int* range_site(const char* what) {
-        const int k = n_sites + 1 < r2dm_handle::RANGE_SITES ? ++n_sites : 0;  // (beyond the table: the shared slot 0 -- still guarded, just not named)
+        static const bool shared = getenv("R2DM_RANGE_SHARED") != nullptr;  // (probe: one slot for the whole forward, as until round 5 -- profiles/r06_range_slots.txt)
+        const int k = shared ? 0 : n_sites + 1 < r2dm_handle::RANGE_SITES ? ++n_sites : 0;  // (beyond the table: the shared slot 0 -- still guarded, just not named)
         if ((int)h->site_names.size() <= k) h->site_names.resize(k + 1);
         h->site_names[k] = ctx.empty() ? std::string(what) : ctx + ": " + what;
         return (int*)blob(h->range_flag) + 2 * k;
@@ -1052,7 +1053,11 @@ int r2dm_check_range(r2dm_handle* h, void* stream) {
     }
     h->sites_read = (int)h->site_names.size() < NS ? (int)h->site_names.size() : NS;
     bound = h->site_bounds[worst];
-    if (any) {  // per forward: reset, so that the next check reports what ran after this one ([0], the packers' weight flag, stays)
+    // The bounds are RUNNING maxima and stay after a clean check; they are reset only when this check reports a trip, so that the check after the fallback reports
+    // what ran since ([0], the packers' weight flag, stays).  Round 6: with one slot per site a reset at every check (every 8-32 steps of a sampler) sent each tracked
+    // site's next launch into a storm of atomicMax on a zeroed slot -- every wave of fir_up2 beats a bound of 0 -- +8 us on each of those launches, 25 us per step in
+    // the traced average (scripts/jobs/j425.sh); one slot for the whole forward (round 5) hid that behind the first GroupNorm's bound.
+    if (any && !(bound < 65504.f)) {
         HIP_TRY(hipMemsetAsync(h->blob + h->range_flag + 1, 0, (2 * NS - 1) * sizeof(int), st));
         HIP_TRY(hipStreamSynchronize(st));
     }

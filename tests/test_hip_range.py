@@ -365,3 +365,6 @@ def test_checkpoint_preflight_on_both_sides_of_the_trip_point(capsys):
     # the default synthetic checkpoint itself: far inside the range
     base = check.preflight(synthetic_ckpt(), num_steps=4, batch=1, device=DEV)
     assert base["trips"] == [] and base["sites"][0][1] < 0.05 * 65504.0
+    # ... and a discrete-time checkpoint (the sampler walks integer timesteps: /root/reference/models/diffusion/discrete_time.py:182-201)
+    disc = check.preflight(synthetic_ckpt(timestep_type="discrete", num_training_steps=1000, noise_schedule="linear"), num_steps=4, batch=1, device=DEV)
+    assert disc["condition"] == "timestep" and disc["trips"] == [] and len(disc["sites"]) > 40

@@ -1,0 +1,14 @@
+#!/bin/bash
+# prologue order A/B: bench alternating old order (lib_prov1.so) and new (lib_pronew.so = the in-tree library)
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/j429; mkdir -p $O
+cd $R
+A="--no-cpu-baseline --no-torch-baseline --no-exact-baseline --no-other-configs"
+for i in 1 2 3 4 5; do
+  for l in prov1 pronew; do
+    R2DM_HIP_LIB=$R/build_probe/lib_$l.so timeout 300 python bench.py $A --steps 128 --warmup 4 2>$O/err_$l.log | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench lib=$l', round(j['ms_per_step'],3), round(j['value'],3), round(j['roofline']['frac'],4))"
+  done
+done | tee $O/ab.log
+tail -5 $O/err_pronew.log

@@ -524,7 +524,9 @@ struct Ctx {
             // same x tile, the stagers bound a chunk at 4.5 k cycles for 1.7 k of MFMAs) take their input through the operand pre-pass with the GroupNorm
             // folded into THAT pass (presplit_fold_kernel): bit-identical; the convolutions go 43.8 -> 28.7 us and 78.3 -> 51.7 us, and the six 12.4 us passes
             // (a launch + three dependent round trips over an 8 MB tensor) take it all back: step 5.894 | 5.895 ms (profiles/r06_narrow_presplit.txt).
-            if (k && narrow_presplit() && L.f2 && L.f2_cot == 32 && L.f2_rows == 4 && h->conv_pieces == 2 && G == 8 && k.C == L.cin && presplit_supported(x, L.cin, H, W)) {
+            // (=2: also the 512 -> 512 launches of level 4 on 64-channel tiles, eight output-channel tiles per x tile as well)
+            const bool narrow_tile = L.f2_cot == 32 || (narrow_presplit() >= 2 && L.f2_cot == 64 && L.cout >= 512);
+            if (k && narrow_presplit() && L.f2 && narrow_tile && L.f2_rows == 4 && h->conv_pieces == 2 && G == 8 && k.C == L.cin && presplit_supported(x, L.cin, H, W)) {
                 fold = false;
                 pre_fold = true;
             }
@@ -679,9 +681,9 @@ struct Ctx {
         static const bool on = !getenv("R2DM_FP16_STORAGE") || atoi(getenv("R2DM_FP16_STORAGE")) != 0;
         return on && h->conv_pieces == 1 && L.f2 && !(L.f2_cot == 32 && narrow_split());
     }
-    static bool narrow_presplit() {
+    static int narrow_presplit() {
         const char* e = getenv("R2DM_F2_PRESPLIT_NARROW");  // (read per call, like R2DM_GN_FOLD: the bit-identity test builds one model per setting)
-        return e && atoi(e) != 0;
+        return e ? atoi(e) : 0;
     }
     // (experiment switch, round 5) layers packed for the 32-channel tile run the two-plane kernel in every precision mode
     static bool narrow_split() {

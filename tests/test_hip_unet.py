@@ -439,7 +439,7 @@ def test_operand_prepass_with_folded_group_norm_is_bit_identical(res, batch):
     x, c = rnd(9, batch, 2, *res).to(DEV), torch.linspace(-5.0, 7.0, batch).to(DEV)
     outs = {}
     saved = os.environ.get("R2DM_F2_PRESPLIT_NARROW")
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):  # (2: the 512 -> 512 launches of level 4 as well)
         os.environ["R2DM_F2_PRESPLIT_NARROW"] = mode
         try:
             m, _, _ = r2dm_amd.setup_model(ck, device=DEV, show_info=False, max_batch=batch)
@@ -452,8 +452,8 @@ def test_operand_prepass_with_folded_group_norm_is_bit_identical(res, batch):
             os.environ.pop("R2DM_F2_PRESPLIT_NARROW", None)
             if saved is not None:
                 os.environ["R2DM_F2_PRESPLIT_NARROW"] = saved
-    assert torch.equal(outs["1"][0], outs["1"][1]) and torch.equal(outs["0"][0], outs["0"][1])
-    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][0], outs["1"][1]) and torch.equal(outs["0"][0], outs["0"][1]) and torch.equal(outs["2"][0], outs["2"][1])
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["2"][0], outs["0"][0])
 
 
 @pytest.mark.parametrize("res,batch", [((64, 1024), 8), ((32, 256), 2), ((128, 2048), 2)])

@@ -126,6 +126,10 @@ int r2dm_profile_enable(r2dm_handle* h, int32_t on);
 int r2dm_profile_read(r2dm_handle* h, double* conv_ms, double* conv_flop, int64_t* launches);
 /* same, per kernel class: [0] conv_f16x2_kernel, [1] conv_bf16x3_*, [2] conv_mfma_kernel / conv_direct_kernel */
 int r2dm_profile_read_classes(r2dm_handle* h, double* ms3, double* flop3, int64_t* launches3);
+/* what a bracketing event pair adds to the kernel between its events, measured on `stream` (medians of 33): the pair around nothing (marker processing)
+ * and around an empty kernel (marker processing + one dispatch + that kernel's own microsecond); bench.py prints both next to the per-launch figures,
+ * which rocprofv3's kernel durations (profiles/) do not contain. */
+int r2dm_profile_event_overhead(r2dm_handle* h, void* stream, double* empty_pair_us, double* empty_kernel_pair_us);
 
 /* -- posterior update: replaces the elementwise tail of p_step
  *    (continuous_time.py:208-229, discrete_time.py:140-177).  coef is (B,8) host-computed scalars,

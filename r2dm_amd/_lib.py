@@ -75,6 +75,7 @@ SIGNATURES = {
     "r2dm_profile_enable": (c_int32, [_P, c_int32]),
     "r2dm_profile_read": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "r2dm_profile_read_classes": (c_int32, [_P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "r2dm_profile_event_overhead": (c_int32, [_P, _P, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "r2dm_posterior_step": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_float, _P]),
     "r2dm_repaint_blend": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
     "r2dm_q_step": (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P]),

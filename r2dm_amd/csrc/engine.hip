@@ -1210,6 +1210,38 @@ int r2dm_profile_enable(r2dm_handle* h, int32_t on) {
     return 0;
 }
 
+// What a bracketing event pair adds to the kernel it brackets (bench.py prints it next to the per-launch figures): the pair around nothing, and around
+// an empty kernel -- marker processing, and marker processing + one dispatch + that kernel's own microsecond.  Medians of 33.
+__global__ void empty_kernel() {}
+int r2dm_profile_event_overhead(r2dm_handle* h, void* stream, double* empty_pair_us, double* empty_kernel_pair_us) {
+    if (!h || !empty_pair_us || !empty_kernel_pair_us) return fail(1, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(2, "hipEventCreate"); }
+    int rc = 0;
+    for (int with_kernel = 0; with_kernel < 2 && rc == 0; ++with_kernel) {
+        std::vector<float> t;
+        for (int i = 0; i < 36 && rc == 0; ++i) {
+            hipError_t e = hipEventRecord(e0, st);
+            if (with_kernel) empty_kernel<<<1, 64, 0, st>>>();
+            if (e == hipSuccess) e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) rc = fail(2, "event pair calibration: %s", hipGetErrorString(e));
+            else if (i >= 3) t.push_back(ms);  // (the first pairs pay for the code object)
+        }
+        if (rc == 0) {
+            std::sort(t.begin(), t.end());
+            (with_kernel ? *empty_kernel_pair_us : *empty_pair_us) = 1e3 * (double)t[t.size() / 2];
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int r2dm_profile_read_classes(r2dm_handle* h, double* ms3, double* flop3, int64_t* launches3) {
     if (!h || !ms3 || !flop3 || !launches3) return fail(1, "null argument");
     for (int c = 0; c < 3; ++c) { ms3[c] = 0.0; flop3[c] = 0.0; launches3[c] = 0; }

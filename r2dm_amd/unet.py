@@ -397,6 +397,15 @@ class EfficientUNet(nn.Module):
         _lib.check(_lib.lib().r2dm_profile_read_classes(self._engine.h, ms, fl, n))
         return [(self.CONV_CLASSES[i], ms[i], fl[i], n[i]) for i in range(3)]
 
+    def event_pair_overhead(self):
+        """-> (microseconds an event pair spans around nothing, around an empty kernel) on the current stream: what the per-launch
+        figures of profile_convs() contain beyond the kernel's own duration (rocprofv3's figure)."""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        dev = self._engine.blob.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().r2dm_profile_event_overhead(self._engine.h, _lib.stream_ptr(dev), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     # -- the hot path ----------------------------------------------------------------------------
     @torch.compiler.disable  # one ctypes call into libr2dm_hip.so: nothing for a tracing compiler to see (runs eagerly under
     def forward(self, images: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:  # torch.compile, sample_and_save.py:45)

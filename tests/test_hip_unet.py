@@ -550,3 +550,10 @@ def test_batch8_full_size_sampler_vs_fp64_oracle_on_the_gpu():
         assert d.max().item() < 2e-3 and (d > 1e-4).sum().item() <= 64, (d.max().item(), (d > 1e-4).sum().item())
         worst = max(worst, d.max().item())
     print(f"batch-8 sampler final sample: max|hip - fp64| = {worst:.2e}")
+
+
+def test_event_pair_overhead_calibration(small):
+    """bench.py's per-launch figures are event pairs around each convolution; r2dm_profile_event_overhead says what such a pair spans by itself
+    (around nothing <= around an empty kernel, both a few microseconds), so that they can be set against rocprofv3's kernel durations."""
+    a, b = small[0].model.event_pair_overhead()
+    assert 0.0 < a <= b + 0.5 and b < 100.0, (a, b)

@@ -107,7 +107,8 @@ int r2dm_set_conv_pieces(r2dm_handle* h, int32_t pieces);
 int r2dm_check_range(r2dm_handle* h, void* stream);
 
 /* Per-site view of the guard (round 6; python -m r2dm_amd.check): a SITE is one guarded producer of a forward in walk order -- a GroupNorm's
- * output bound, or the recorded max|output| of a tensor that the next fp16-operand kernel reads raw.  r2dm_range_sites copies the bounds
+ * output bound, or the recorded max|output| of a tensor that the next fp16-operand kernel reads raw (conv_f16x2 records the root of the largest sum of squares of four
+ * neighbouring pixels: an upper bound of max|output|, at most twice it).  r2dm_range_sites copies the bounds
  * the LAST r2dm_check_range read (up to `cap`; *n = number of sites of the last forward, site 0 = shared slot) -- call r2dm_check_range
  * first; r2dm_range_site_name labels site k ("d_block1.residual_blocks.0.conv1: GroupNorm output bound ..."; valid until the next forward).
  * A bound >= 65504 is a trip.  Replaces nothing upstream: the reference runs fp32 / autocast and has no operand range to guard. */

@@ -118,6 +118,37 @@ __device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, double
     }
 }
 
+// conv_f16x2.hip's tile ends (round 6): the wave's share of a statistics slot -- 2 quarters x 64 lanes x 4 pixels of an 8-channel block, 512 values -- is summed in
+// fp32 (pairwise: 2 + 1 + 6 butterfly levels, ~1e-7 relative, unbiased and independent from slot to slot: a group's >= 128 slots average it down to ~1e-8), fp64 from
+// the slot on (gn_finalize / the folded GroupNorm).  One instruction per exchange instead of two plus a half-rate add and sixteen conversions: with the range maximum
+// taken from the sums of squares, -0.9 % on the step (profiles/r06_tile_end_diet.txt); -DF2_STATS_F64 restores the fp64 butterfly above.
+__device__ __forceinline__ void epi_stat_write_bfly8(const ConvParams& p, float (&st_s)[4], float (&st_q)[4], int b, int th,
+                                                     int tw, int nTw, int co_half, int wave_px, int lane) {
+    using gdouble = double __attribute__((address_space(1)))*;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = st_s[j];
+        v[2 * j + 1] = st_q[j];
+    }
+    float t = wave_sum8_scatter(v, lane);
+    const int bpg = p.stat_cpg >> 3;
+    if (bpg >= 2) wave_swap_add(t, t, true);
+    if (bpg >= 4) wave_swap_add(t, t, false);
+    const int k8 = (lane >> 4) & 3, kind = (lane >> 3) & 1;
+    const int bin = bpg < 4 ? bpg : 4;
+    if ((lane & 7) == 0 && (k8 & (bin - 1)) == 0) {
+        const int S = p.stat_slots >> 1;
+        const int slot = (th * nTw + tw) * 4 + wave_px;
+        const int sh = 3 + (bpg >= 2) + (bpg >= 4) + (bpg >= 8);
+        const int g = p.stat_goff + ((co_half + k8 * 8) >> sh);
+        const int half = bpg == 8 ? (co_half & (p.stat_cpg - 1)) >> 5 : 0;
+        gdouble o = (gdouble)(p.stat + (((size_t)b * p.stat_G + g) * p.stat_slots + slot) * 2);
+        o[2 * S * half + kind] = (double)t;
+        if (bpg < 8) o[2 * S + kind] = 0.0;
+    }
+}
+
 // ---- wide epilogue (whole tiles: H % TH == 0, W % TW == 0, Cout % (32 MR) == 0) --------------------------------------
 // The MFMA layout gives a lane ONE pixel of 16 channels, i.e. 4-byte global accesses, 256 B per instruction -- and a CU
 // retires those at a few bytes per cycle (in-kernel timeline of round 2: the residual loads + stores of one 64 x 256 tile

@@ -894,24 +894,42 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                         v = rv[k][k8] + v;  // (without a residual the buffers stay zero)
                         v *= sc_blk;
                         (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
+#ifdef F2_RANGE_ELEMENTWISE
                         if (p.range) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#endif
                         ps[k & 1][k8] = (v[0] + v[1]) + (v[2] + v[3]);
                         pq[k & 1][k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+#ifndef F2_RANGE_ELEMENTWISE
+                        amax = fmaxf(amax, pq[k & 1][k8]);
+#endif
                     }
                     if ((k & 1) && p.stat) {  // a pair of quarters = one image row of one 32-channel half = one statistics slot: the multipliers' half_stats
+#ifndef F2_STATS_F64
+                        float st_s[4], st_q[4];
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {
+                            st_s[k8] = ps[0][k8] + ps[1][k8];
+                            st_q[k8] = pq[0][k8] + pq[1][k8];
+                        }
+#else
                         double st_s[4], st_q[4];
 #pragma unroll
                         for (int k8 = 0; k8 < 4; ++k8) {
                             st_s[k8] = (double)ps[0][k8] + (double)ps[1][k8];
                             st_q[k8] = (double)pq[0][k8] + (double)pq[1][k8];
                         }
+#endif
                         const int mm = qd >> 1;
                         if constexpr (NR == 4) epi_stat_write_bfly8(p, st_s, st_q, b, 2 * th + (wave >> 1), tw, nTw, cot * COT + (mm >> 1) * 32, 2 * (wave & 1) + (mm & 1), ln);
                         else epi_stat_write_bfly8(p, st_s, st_q, b, th, tw, nTw, cot * COT + mm * 32, wave, ln);
                     }
                 }
                 if (p.range) {
+#ifndef F2_RANGE_ELEMENTWISE
+                    const float a = sqrtf(wave_max_f32(amax)) * 1.000001f;
+#else
                     const float a = wave_max_f32(amax);
+#endif
                     const int bits = __float_as_int(a);
                     if (ln == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
                 }
@@ -1268,9 +1286,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
                 (yu + (long)(m * 32 + k8 * 8) * (HW >> 2))[off] = v;
 #endif
             }
+#ifdef F2_RANGE_ELEMENTWISE
             if (p.range) amax_e = fmaxf(fmaxf(amax_e, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#endif
             ps[k8] = (v[0] + v[1]) + (v[2] + v[3]);
             pq[k8] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+#ifndef F2_RANGE_ELEMENTWISE
+            // Round 6: the range maximum rides on the statistics -- max over the sums of squares of four pixels, one instruction, no branch; its root
+            // (range_flush) bounds max|y| from above by at most a factor 2.  Element by element it was seven instructions behind a wave-uniform
+            // branch per store (the ISA: two taken branches per 16-byte store in the launches that do not track a range at all): -0.6 % on the step
+            // (profiles/r06_tile_end_diet.txt).  An infinite or overflowing output gives an infinite sum: still a trip.
+            amax_e = fmaxf(amax_e, pq[k8]);
+#endif
         }
     };
     auto half_stats = [&](auto M, const float (&s0)[4], const float (&q0)[4], const float (&s1)[4], const float (&q1)[4], int b, int th,
@@ -1279,12 +1306,21 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
 #ifdef F2_NO_STORE
         if (ln >= 0) return;
 #endif
+#ifndef F2_STATS_F64
+        float st_s[4], st_q[4];
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            st_s[k8] = s0[k8] + s1[k8];
+            st_q[k8] = q0[k8] + q1[k8];
+        }
+#else
         double st_s[4], st_q[4];
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {  // (four pixels in fp32, fp64 beyond: conv_epilogue.h)
             st_s[k8] = (double)s0[k8] + (double)s1[k8];
             st_q[k8] = (double)q0[k8] + (double)q1[k8];
         }
+#endif
         // M = index of a pair of quarters (2 M, 2 M + 1): one image row of one 32-channel half -- a statistics slot.  Four-row tiles: the
         // half is M, the slot (tile, wave).  The eight-row tile's wave owns rows 2 wave, 2 wave + 1: half M / 2, and the slot is the one the
         // four-row tiling gives that row -- tile row 2 th + wave / 2, "wave" 2 (wave % 2) + M % 2: same slots, same sums, same order.
@@ -1294,7 +1330,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvParams p, 
     };
     auto range_flush = [&](int ln) __attribute__((always_inline)) {
         if (!p.range) return;
+#ifndef F2_RANGE_ELEMENTWISE
+        const float a = sqrtf(wave_max_f32(amax_e)) * 1.000001f;
+#else
         const float a = wave_max_f32(amax_e);
+#endif
         const int bits = __float_as_int(a);  // positive floats order like their bit patterns
         if (ln == 0 && bits > __atomic_load_n(p.range + 1, __ATOMIC_RELAXED)) atomicMax(p.range + 1, bits);
         amax_e = 0.f;

@@ -107,6 +107,29 @@ __device__ __forceinline__ double wave_sum8_scatter(double (&v)[8], int lane) {
     t += wave_dpp<0x141>(t);
     return t;
 }
+// the same reduce-scatter on fp32 values (conv_f16x2.hip's tile ends): one instruction per exchange instead of two plus a half-rate add
+__device__ __forceinline__ void wave_swap_add(float& a, const float b, bool rows16) {
+    if (rows16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+__device__ __forceinline__ float wave_sum8_scatter(float (&v)[8], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wave_swap_add(v[i], v[i + 4], false);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wave_swap_add(v[i], v[i + 2], true);
+    const bool up = lane & 8;
+    const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    float t = keep + wave_dpp<0x128>(send);
+    t += wave_dpp<0xB1>(t);
+    t += wave_dpp<0x4E>(t);
+    t += wave_dpp<0x141>(t);
+    return t;
+}
 // ... and gathered: every lane gets all eight totals (v_readlane: wave-uniform results)
 __device__ __forceinline__ void wave_sum8(double (&v)[8], int lane) {
     const double t = wave_sum8_scatter(v, lane);

@@ -156,18 +156,30 @@ __global__ __launch_bounds__(512) void attention_f16x2_kernel(const float* __res
     const float* vp = kp + (long)C * N;
 
     // Q: B operand of S^T, lane (query l31, half hi) holds d = 16 s + 8 hi + 0..7 of k-step s; scaled, split once
+    // (Round 6, read in the ISA: as `active ? qp[...] * scale : 0` every one of these D / 2 loads sat in its own exec-masked branch with an s_waitcnt vmcnt(0) behind
+    // it -- 32 SERIAL round trips before the first key tile.  Now all of them are in flight at once, from an address that is valid in every wave.)
     u32x4 qh[KS], ql[KS];
+    {
+        const float* qcol = qp + (active ? q0 : 0) + l31;
+        float qa[KS][4], qc[KS][4];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = active ? qp[(long)(s * 16 + hi * 8 + 2 * j) * N + q0 + l31] * scale : 0.f;
-            const float c = active ? qp[(long)(s * 16 + hi * 8 + 2 * j + 1) * N + q0 + l31] * scale : 0.f;
-            unsigned uh, ul;
-            split_f16x2(a, c, uh, ul);
-            qh[s][j] = uh;
-            ql[s][j] = ul;
-        }
+            for (int j = 0; j < 4; ++j) {
+                qa[s][j] = qcol[(long)(s * 16 + hi * 8 + 2 * j) * N];
+                qc[s][j] = qcol[(long)(s * 16 + hi * 8 + 2 * j + 1) * N];
+            }
+        const float qs = active ? scale : 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned uh, ul;
+                split_f16x2(qa[s][j] * qs, qc[s][j] * qs, uh, ul);
+                qh[s][j] = uh;
+                ql[s][j] = ul;
+            }
+    }
 
     f32x16 o[TB], ol[TB];
 #pragma unroll

@@ -95,39 +95,66 @@ __device__ __forceinline__ void fir_down2_patch(const float* __restrict__ xp, lo
     // (SHFL) byte addresses of the lanes holding column quads t - 1 and t + 1 of this row (Wq is a power of two here)
     const int lsrc = SHFL == 1 ? (((lane & ~(Wq - 1)) | ((t - 1) & (Wq - 1))) << 2) : (lane - 1) << 2, rsrc = SHFL == 1 ? (((lane & ~(Wq - 1)) | ((t + 1) & (Wq - 1))) << 2) : (lane + 1) << 2;
     float h[6][4];  // horizontally filtered rows 4 i2 - 1 .. 4 i2 + 4 at the four output columns
+    if constexpr (SHFL != 0) {
+        // Round 6 (read in the ISA): with the loads of a row inside `if (row inside the image)`, each row was an exec-masked block of its own with an s_waitcnt vmcnt(0)
+        // behind it -- the lane exchange needs the values --: six serial round trips per patch, and the edge lanes' halo loads six more.  Now every row is loaded from a
+        // clamped (valid) row index up front, twelve vectors in flight, the edge lanes fetch their six halo values in one block, and a row outside the image is zeroed
+        // where it always was: after the horizontal filter.  Same operands into the same fir4 chains: bit-identical outputs.
+        f32x4 m0[6], m1[6];
+        bool in[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const int r = 4 * i2 + a - 1;
-        const bool in = r >= 0 && r < H;
-        if constexpr (SHFL != 0) {
-            f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
-            if (in) {
-                m0 = load4<X16>(xp, e0 + (long)r * W + 8 * t);
-                m1 = load4<X16>(xp, e0 + (long)r * W + 8 * t + 4);
+        for (int a = 0; a < 6; ++a) {
+            const int r = 4 * i2 + a - 1;
+            in[a] = r >= 0 && r < H;
+            const long er = e0 + (long)(r < 0 ? 0 : r >= H ? H - 1 : r) * W;
+            m0[a] = load4<X16>(xp, er + 8 * t);
+            m1[a] = load4<X16>(xp, er + 8 * t + 4);
+        }
+        float le[6] = {}, re[6] = {};
+        if constexpr (SHFL == 2) {  // (lane % 64 == t % 64: the first and last lane of a wave have their neighbour in another wave -- or across the seam)
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int r = 4 * i2 + a - 1;
+                    const long er = e0 + (long)(r < 0 ? 0 : r >= H ? H - 1 : r) * W;
+                    const float e = load1<X16>(xp, er + (lane == 0 ? cl : cr));
+                    le[a] = e;
+                    re[a] = e;
+                }
             }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
             // (all lanes take part in the exchange; lanes of another row pair may be outside the image while this one is inside: their values are
             // not read by anybody of this row)
-            float l = __int_as_float(__builtin_amdgcn_ds_bpermute(lsrc, __float_as_int(m1[3])));
-            float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(rsrc, __float_as_int(m0[0])));
-            if constexpr (SHFL == 2) {  // (lane % 64 == t % 64: the first and last lane of a wave have their neighbour in another wave -- or across the seam)
-                if (in && lane == 0) l = load1<X16>(xp, e0 + (long)r * W + cl);
-                if (in && lane == 63) rr = load1<X16>(xp, e0 + (long)r * W + cr);
+            float l = __int_as_float(__builtin_amdgcn_ds_bpermute(lsrc, __float_as_int(m1[a][3])));
+            float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(rsrc, __float_as_int(m0[a][0])));
+            if constexpr (SHFL == 2) {
+                l = lane == 0 ? le[a] : l;
+                rr = lane == 63 ? re[a] : rr;
             }
-            h[a][0] = in ? fir4(l, m0[0], m0[1], m0[2]) : 0.f;
-            h[a][1] = in ? fir4(m0[1], m0[2], m0[3], m1[0]) : 0.f;
-            h[a][2] = in ? fir4(m0[3], m1[0], m1[1], m1[2]) : 0.f;
-            h[a][3] = in ? fir4(m1[1], m1[2], m1[3], rr) : 0.f;
-        } else if (in) {
-            const long er = e0 + (long)r * W;
-            const f32x4 m0 = load4<X16>(xp, er + 8 * t), m1 = load4<X16>(xp, er + 8 * t + 4);
-            const float l = load1<X16>(xp, er + cl), rr = load1<X16>(xp, er + cr);
-            h[a][0] = fir4(l, m0[0], m0[1], m0[2]);
-            h[a][1] = fir4(m0[1], m0[2], m0[3], m1[0]);
-            h[a][2] = fir4(m0[3], m1[0], m1[1], m1[2]);
-            h[a][3] = fir4(m1[1], m1[2], m1[3], rr);
-        } else {
+            h[a][0] = in[a] ? fir4(l, m0[a][0], m0[a][1], m0[a][2]) : 0.f;
+            h[a][1] = in[a] ? fir4(m0[a][1], m0[a][2], m0[a][3], m1[a][0]) : 0.f;
+            h[a][2] = in[a] ? fir4(m0[a][3], m1[a][0], m1[a][1], m1[a][2]) : 0.f;
+            h[a][3] = in[a] ? fir4(m1[a][1], m1[a][2], m1[a][3], rr) : 0.f;
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[a][j] = 0.f;
+        for (int a = 0; a < 6; ++a) {
+            const int r = 4 * i2 + a - 1;
+            const bool in = r >= 0 && r < H;
+            if (in) {
+                const long er = e0 + (long)r * W;
+                const f32x4 m0 = load4<X16>(xp, er + 8 * t), m1 = load4<X16>(xp, er + 8 * t + 4);
+                const float l = load1<X16>(xp, er + cl), rr = load1<X16>(xp, er + cr);
+                h[a][0] = fir4(l, m0[0], m0[1], m0[2]);
+                h[a][1] = fir4(m0[1], m0[2], m0[3], m1[0]);
+                h[a][2] = fir4(m0[3], m1[0], m1[1], m1[2]);
+                h[a][3] = fir4(m1[1], m1[2], m1[3], rr);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[a][j] = 0.f;
+            }
         }
     }
 #pragma unroll
@@ -225,21 +252,18 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
         const int cr = 2 * t + 2 >= W ? 0 : 2 * t + 2;
         float h[3][4];  // horizontally upsampled rows i-1, i, i+1 at output columns 4t..4t+3
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int r = i + a - 1;
-            if (r >= 0 && r < H) {
-                const long er = e0 + (long)r * W;
-                float2 m;
-                if constexpr (X16) m = make_float2(load1<true>(x, er + 2 * t), load1<true>(x, er + 2 * t + 1));
-                else m = *reinterpret_cast<const float2*>(x + er + 2 * t);
-                const float l = load1<X16>(x, er + cl), rr = load1<X16>(x, er + cr);
-                h[a][0] = up1(l, m.x);
-                h[a][1] = up1(m.y, m.x);
-                h[a][2] = up1(m.x, m.y);
-                h[a][3] = up1(rr, m.y);
-            } else {
-                h[a][0] = h[a][1] = h[a][2] = h[a][3] = 0.f;
-            }
+        for (int a = 0; a < 3; ++a) {  // (round 6: every row loaded from a valid row index, nine loads in flight; a row outside the image is zeroed behind its filter --
+            const int r = i + a - 1;   //  inside `if (row inside)` each row was a block of its own with a full wait behind it)
+            const bool in = r >= 0 && r < H;
+            const long er = e0 + (long)(in ? r : i) * W;
+            float2 m;
+            if constexpr (X16) m = make_float2(load1<true>(x, er + 2 * t), load1<true>(x, er + 2 * t + 1));
+            else m = *reinterpret_cast<const float2*>(x + er + 2 * t);
+            const float l = load1<X16>(x, er + cl), rr = load1<X16>(x, er + cr);
+            h[a][0] = in ? up1(l, m.x) : 0.f;
+            h[a][1] = in ? up1(m.y, m.x) : 0.f;
+            h[a][2] = in ? up1(m.x, m.y) : 0.f;
+            h[a][3] = in ? up1(rr, m.y) : 0.f;
         }
         f32x4 e, o;
 #pragma unroll
@@ -287,16 +311,33 @@ __global__ __launch_bounds__(256) void fir_up2_wide_kernel(const float* __restri
         const int cl = 4 * t - 1 < 0 ? W - 1 : 4 * t - 1;
         const int cr = 4 * t + 4 >= W ? 0 : 4 * t + 4;
         float h[3][8];  // horizontally upsampled rows i-1, i, i+1 at output columns 8t .. 8t+7
+        // (round 6, as fir_down2_patch: the three rows' vectors in flight together, the edge lanes' halo values fetched in ONE divergent block -- per row they were
+        // two blocks with a full wait each)
+        f32x4 mr[3];
+        bool inr[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int r = i + a - 1;
-            const bool in = r >= 0 && r < H;  // (rows i-1 / i+1 of lanes in other rows of the wave may differ: every lane takes part in the exchange)
-            const long er = e0 + (long)(in ? r : i) * W;
-            const f32x4 m = load4<X16>(x, er + 4 * t);
+            inr[a] = r >= 0 && r < H;  // (rows i-1 / i+1 of lanes in other rows of the wave may differ: every lane takes part in the exchange)
+            mr[a] = load4<X16>(x, e0 + (long)(inr[a] ? r : i) * W + 4 * t);
+        }
+        float le[3] = {}, re[3] = {};
+        if (!lsh || !rsh) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const long er = e0 + (long)(inr[a] ? i + a - 1 : i) * W;
+                if (!lsh) le[a] = load1<X16>(x, er + cl);
+                if (!rsh) re[a] = load1<X16>(x, er + cr);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const bool in = inr[a];
+            const f32x4 m = mr[a];
             float l = __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 1) << 2, __float_as_int(m[3])));
             float rr = __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) << 2, __float_as_int(m[0])));
-            if (!lsh) l = load1<X16>(x, er + cl);
-            if (!rsh) rr = load1<X16>(x, er + cr);
+            l = lsh ? l : le[a];
+            rr = rsh ? rr : re[a];
             h[a][0] = in ? up1(l, m[0]) : 0.f;
             h[a][1] = in ? up1(m[1], m[0]) : 0.f;
             h[a][2] = in ? up1(m[0], m[1]) : 0.f;

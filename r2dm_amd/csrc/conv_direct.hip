@@ -74,6 +74,60 @@ __global__ __launch_bounds__(256) void conv_direct_rows_kernel(const ConvParams 
 #ifndef DC_UNROLL
 #define DC_UNROLL 4  // (one wave per SIMD: the loads in flight hide the latency -- 2: 65.6 us, 4: 52.8 us, 8: 64.0 us at batch 8)
 #endif
+    if constexpr (X16) {
+        // fp16 input (the one-plane mode's out_conv), a loop of its own since round 6: through the shared body below the compiler converted every row behind a full wait --
+        // ~8 serial round trips per channel, 133 us per launch at batch 8 for HALF the bytes of the fp32 launch (52 us); read in the ISA, profiles/r06_tile_end_diet.txt.
+        // Here the raw halves of two channels (2 x (R + 2) rows x 3 loads) are requested before the first conversion: 133 -> 52 us.  Same values into the same FMA order: bit-identical.
+        using gcu = const unsigned long long __attribute__((address_space(1)))*;
+        using gch = const unsigned short __attribute__((address_space(1)))*;
+        const unsigned short* h0 = reinterpret_cast<const unsigned short*>(xb0);
+        const unsigned short* h1 = reinterpret_cast<const unsigned short*>(xb1);
+#ifndef DC16_BATCH
+#define DC16_BATCH 2  // (channels per load batch at batch 8: 1: 53.0 us, 2: 52.3 us, 4: 70.8 us, 8: 68.4 us -- more registers, fewer waves; scripts/jobs/j446.sh)
+#endif
+        constexpr int NB = DC16_BATCH;
+        for (int cb = 0; cb < p.Cin; cb += NB) {  // (Cin % 2 == 0: launcher)
+            unsigned long long rv[NB][R + 2];
+            unsigned short rl[NB][R + 2], rr[NB][R + 2];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int ci = cb + u;
+                const unsigned short* pl = ci < c0 ? h0 + (long)ci * HW : h1 + (long)(ci - c0) * HW;
+#pragma unroll
+                for (int k = 0; k < R + 2; ++k) {
+                    rv[u][k] = *(gcu)(pl + rbase[k] + gc);
+                    rl[u][k] = ((gch)pl)[rbase[k] + cl];
+                    rr[u][k] = ((gch)pl)[rbase[k] + cr];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int ci = cb + u;
+                float x[R + 2][6];
+#pragma unroll
+                for (int k = 0; k < R + 2; ++k) {
+                    const f32x4 v = f16x4_to_f32(rv[u][k]);
+                    const float l = (float)__builtin_bit_cast(_Float16, rl[u][k]), r = (float)__builtin_bit_cast(_Float16, rr[u][k]);
+                    x[k][0] = rok[k] ? l : 0.f;
+                    x[k][5] = rok[k] ? r : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[k][1 + j] = rok[k] ? v[j] : 0.f;
+                }
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const gcf wk = wg + ((long)o * p.Cin + ci) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float w = wk[t];
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[o][i][j] = fmaf(w, x[i + t / 3][j + t % 3], acc[o][i][j]);
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll DC_UNROLL
     for (int ci = 0; ci < p.Cin; ++ci) {
         // (the fp32 path is round 5's code to the letter: restructured around a shared loop body it compiled to 72 instead of 122 registers -- fewer loads in
@@ -271,6 +325,7 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t s) {
         const unsigned nb = (unsigned)(((p.W + 255) / 256) * ((p.H + 4 * DC_ROWS - 1) / (4 * DC_ROWS)) * p.B);
         if (p.y16) return hipErrorInvalidValue;  // (the network output is fp32)
         if (p.x16) {
+            if (p.Cin % 2) return hipErrorInvalidValue;  // (the fp16-input loop walks the channels two at a time)
             switch (p.Cout) {
                 case 1: conv_direct_rows_kernel<1, true><<<nb, 256, 0, s>>>(p); break;
                 case 2: conv_direct_rows_kernel<2, true><<<nb, 256, 0, s>>>(p); break;

@@ -483,8 +483,8 @@ def main():
             "empty_pair_us": ev_pair[0], "empty_kernel_pair_us": ev_pair[1], "avg_launch_us_raw": dom["avg_launch_us"], "avg_launch_us_band": [lo, hi],
             "frac_band": [dom["frac"] * dom["avg_launch_us"] / hi, dom["frac"] * dom["avg_launch_us"] / lo],
             "note": "an event pair on an idle stream spans empty_pair_us around nothing and empty_kernel_pair_us around an empty kernel (marker processing + one dispatch + "
-                    "that kernel's ~1 us), medians of 33 in this process; rocprofv3's average duration of the same kernel (committed summary: 94.8 us where this figure was 102.2) sits ~1.5 us under the band -- "
-                    "a pair costs that much more on a busy stream than on an idle one"}
+                    "that kernel's ~1 us), medians of 33 in this process; rocprofv3's average duration of the same kernel lies at the band's lower end (profiles/r06d_*: 93.0 us where this figure was 99.1, band 93.0-94.6; "
+                    "r06b: 94.8 against a band of 96.1-97.7 -- a pair costs up to ~1.5 us more on a busy stream than on an idle one)"}
         if bsum and dom.get("products_per_fp32_product"):
             pk = PEAK_BF16 * bsum["sclk_mhz"] / 2400.0 / dom["products_per_fp32_product"] / 1e12
             line["roofline"]["peak_at_sustained_clock"] = pk
